@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference model on CPU.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+sees the reference -- it sees the small .npz fixtures this script writes.
+The reference package __init__ pulls librosa/cv2 (absent here), so the model
+files are imported through stub packages (SURVEY.md section 8c recipe).
+
+Weights and inputs are NOT stored for the large cases: both sides regenerate
+them from speech_separation_amd.spec.synthetic_state_dict / synthetic_inputs
+(numpy PCG64 -> identical on every machine); a sha256 of the weight bytes is
+stored so a drift is detected instead of silently mis-compared.
+
+Usage:  python tools/gen_golden.py            (rewrites tests/golden/)
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speech_separation_amd.spec import (DPTN_AV, DPTN_AUDIO, DPTN_TINY, DPTNConfig,  # noqa: E402
+                                        state_dict_spec, synthetic_inputs, synthetic_state_dict)
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    for name, path in [("src", f"{REF}/src"), ("src.model", f"{REF}/src/model"), ("src.loss", f"{REF}/src/loss")]:
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    sys.path.insert(0, REF)
+    dptn_wav = importlib.import_module("src.model.dptn_wav")
+    losses = importlib.import_module("src.loss.ss_losses")
+    return dptn_wav, losses
+
+
+def weights_digest(sd) -> str:
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    return h.hexdigest()
+
+
+def build_reference(dptn_wav, cfg: DPTNConfig, sd):
+    kw = dict(num_features=cfg.num_features, kernel_size_enc=cfg.kernel_size_enc, hidden_dim=cfg.hidden_dim,
+              num_blocks=cfg.num_blocks, chunk_size=cfg.chunk_size, step_size=cfg.step_size,
+              num_heads=cfg.num_heads, dropout=cfg.dropout, bidir=cfg.bidir)
+    if cfg.audio_only:
+        model = dptn_wav.DPTNWavEncDec(**kw)
+    else:
+        model = dptn_wav.DPTNAVWavEncDec(video_emb_size=cfg.video_emb_size, hidden_video=cfg.hidden_video, **kw)
+    ref_keys = list(model.state_dict().keys())
+    our_keys = [k for k, _ in state_dict_spec(cfg)]
+    assert ref_keys == our_keys, "state_dict key order drifted from spec"
+    for k, s in state_dict_spec(cfg):
+        assert tuple(model.state_dict()[k].shape) == s, (k, s)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return model.eval()
+
+
+def run_with_taps(model, cfg: DPTNConfig, inp):
+    """Forward with hooks -> dict of stage tensors (reference layouts)."""
+    taps = {}
+    hooks = []
+
+    def tap(name, mod, which="out"):
+        def fn(_m, args, out):
+            t = args[0] if which == "in" else out
+            if isinstance(t, (list, tuple)):
+                t = torch.stack(list(t), 0)
+            taps[name] = t.detach().clone().numpy()
+        hooks.append(mod.register_forward_hook(fn))
+
+    tap("enc_conv", model.encoder)                    # A2 (before video fusion)
+    tap("encoded", model.dprnn, "in")                 # A3 fused latent (B,N,L)
+    tap("chunked", model.dprnn.segmenter)             # A4 (B,N,S,K)
+    for b, blk in enumerate(model.dprnn.model):
+        tap(f"blk{b}_intra", blk.intra_chunk_block)   # (B*S,K,N)
+        tap(f"blk{b}_inter", blk.inter_chunk_block)   # (B*K,S,N)
+        tap(f"blk{b}_out", blk)                       # (B,N,S,K)
+    tap("sep", model.dprnn.speakers_separation)       # (B,2N,S,K)
+    tap("ola", model.dprnn.overladd)                  # (B,2N,ola)
+    tap("masks", model.dprnn)                         # stacked (2,B,N,L)
+    with torch.no_grad():
+        batch = {k: torch.from_numpy(v) for k, v in inp.items() if k in ("mix", "s1_embedding", "s2_embedding")}
+        # extra key must be swallowed by **batch exactly like trainer.py:40 passes it
+        out = model(mix_spectrogram=torch.zeros(1), **batch)
+    for h in hooks:
+        h.remove()
+    taps["s1_pred"] = out["s1_pred"].numpy()
+    taps["s2_pred"] = out["s2_pred"].numpy()
+    return taps
+
+
+def loss_and_metric(losses, taps, inp):
+    """A10 (reference code) and A11 (restated: torchmetrics is not installed)."""
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **{k: taps[k] for k in ("s1_pred", "s2_pred")}}.items()}
+    crit = losses.SiSNRWavLoss()
+    loss = crit(s1_pred=t["s1_pred"], s2_pred=t["s2_pred"], s1=t["s1"], s2=t["s2"])["loss"].item()
+    single = losses.SiSNRLoss()
+    pair = {f"sisnr_loss_{a}_{b}": single(t[f"{a}_pred"], t[b]).item() for a in ("s1", "s2") for b in ("s1", "s2")}
+    return {"pit_loss": np.float64(loss), **{k: np.float64(v) for k, v in pair.items()}}
+
+
+def subsample(a: np.ndarray, step: int) -> np.ndarray:
+    return np.ascontiguousarray(a.reshape(-1)[::step])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    dptn_wav, losses = import_reference()
+
+    # ---- 1. tiny config: every stage tensor, weights and inputs stored ----
+    for name, cfg in (("tiny_av", DPTN_TINY), ("tiny_audio", DPTNConfig(**{**DPTN_TINY.to_dict(), "audio_only": True})),
+                      ("tiny_unidir", DPTNConfig(**{**DPTN_TINY.to_dict(), "bidir": False}))):
+        sd = synthetic_state_dict(cfg, seed=7)
+        inp = synthetic_inputs(cfg, B=2, T=209, Tv=9, seed=11)
+        model = build_reference(dptn_wav, cfg, sd)
+        taps = run_with_taps(model, cfg, inp)
+        extra = loss_and_metric(losses, taps, inp)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), cfg=np.array(repr(cfg.to_dict())),
+                            digest=np.array(weights_digest(sd)),
+                            **{f"w.{k}": v for k, v in sd.items()}, **{f"in.{k}": v for k, v in inp.items()},
+                            **{f"tap.{k}": v for k, v in taps.items()}, **{f"val.{k}": v for k, v in extra.items()})
+        print(name, "stages:", len(taps), "loss", extra["pit_loss"])
+
+    # ---- 2. real feature sizes, short audio, 2 blocks: outputs + strided taps ----
+    cases = [
+        ("mid_av", DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2}), dict(B=2, T=8000, Tv=50)),
+        ("mid_audio", DPTNConfig(**{**DPTN_AUDIO.to_dict(), "num_blocks": 2}), dict(B=2, T=8000, Tv=50)),
+        ("full_av", DPTN_AV, dict(B=1, T=32000, Tv=50)),
+    ]
+    for name, cfg, shp in cases:
+        sd = synthetic_state_dict(cfg, seed=0)
+        inp = synthetic_inputs(cfg, seed=123, **shp)
+        model = build_reference(dptn_wav, cfg, sd)
+        taps = run_with_taps(model, cfg, inp)
+        extra = loss_and_metric(losses, taps, inp)
+        keep = {"s1_pred": taps["s1_pred"], "s2_pred": taps["s2_pred"]}
+        for k, v in taps.items():
+            if k not in keep:
+                keep[f"strided97.{k}"] = subsample(v, 97)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), cfg=np.array(repr(cfg.to_dict())),
+                            shape=np.array([shp["B"], shp["T"], shp["Tv"]]), digest=np.array(weights_digest(sd)),
+                            **{f"tap.{k}": v for k, v in keep.items()}, **{f"val.{k}": v for k, v in extra.items()})
+        print(name, "loss", extra["pit_loss"], "rms", float(np.sqrt((taps['s1_pred'] ** 2).mean())))
+
+
+if __name__ == "__main__":
+    main()
