@@ -1,0 +1,132 @@
+/*
+ * dptnav.h -- C ABI of libdptnav.so: the MI355X (gfx950) implementation of the
+ * DPTN / DPTN-AV raw-waveform separation FORWARD path of teasgen/speech_separation.
+ *
+ * What this boundary replaces in the reference (paths relative to /root/reference):
+ *   The reference has no FFI/plugin layer; its boundary for this path is the nn.Module
+ *   duck type consumed by the trainer/inferencer:
+ *     construction  hydra.utils.instantiate(config.model)            train.py:43, inference.py:40
+ *                   kwargs = src/configs/model/dptn_wav_av.yaml:1-12 (dptn_wav.yaml:1-10)
+ *     call          outputs = self.model(**batch)                    src/trainer/trainer.py:40,
+ *                                                                    src/trainer/inferencer.py:117
+ *     body          DPTNAVWavEncDec.forward                          src/model/dptn_wav.py:171-194
+ *                   DPTNWavEncDec.forward (audio only)               src/model/dptn_wav.py:105-117
+ *     checkpoint    state_dict()/load_state_dict()                   src/trainer/base_trainer.py:476,519,557-560
+ *   The Python shim speech_separation_amd/model.py keeps that duck type (same ctor kwargs,
+ *   same forward signature, same state_dict keys) and calls the entry points below through
+ *   ctypes with raw device pointers -- see INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *dev* / every tensor argument is a DEVICE pointer
+ *     to contiguous fp32 owned by the caller (PyTorch-ROCm caching allocator in practice);
+ *   - the library allocates nothing on the hot path: the caller passes a workspace of at
+ *     least dptnav_workspace_bytes() bytes (256-byte aligned);
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void* here so that C callers
+ *     do not need hip headers); nothing synchronises the device;
+ *   - every function returns 0 on success, non-zero on error; the message is retrievable with
+ *     dptnav_last_error().  The library never aborts and never falls back to a CPU path;
+ *   - a handle is bound to the device current at dptnav_create() time and is NOT thread-safe
+ *     (the reference's caller is single-threaded: trainer.py runs under the GIL).
+ */
+#ifndef DPTNAV_H_
+#define DPTNAV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPTNAV_ABI_VERSION 1
+
+/* error codes */
+#define DPTNAV_OK 0
+#define DPTNAV_ERR_INVALID 1     /* bad argument / unsupported shape */
+#define DPTNAV_ERR_WORKSPACE 2   /* workspace too small or misaligned */
+#define DPTNAV_ERR_WEIGHTS 3     /* weights not bound / wrong count */
+#define DPTNAV_ERR_HIP 4         /* a HIP call or launch failed */
+
+/* Constructor arguments of DPTNAVWavEncDec / DPTNWavEncDec (dptn_wav.py:137-150, 72-83). */
+typedef struct dptnav_config {
+  int32_t num_features;    /* N: 128 (dptn_wav_av.yaml:2) or 64 (dptn_wav.yaml:2)              */
+  int32_t video_emb_size;  /* 512; ignored when audio_only                                      */
+  int32_t hidden_video;    /* must equal num_features (it is added to the latent, :184)         */
+  int32_t kernel_size_enc; /* 7 -> stride 3                                                     */
+  int32_t hidden_dim;      /* H: LSTM hidden size, must be 128                                  */
+  int32_t num_blocks;      /* 6                                                                 */
+  int32_t chunk_size;      /* K = 150 (<= 256)                                                  */
+  int32_t step_size;       /* P = 75                                                            */
+  int32_t num_heads;       /* 4; head dim N/heads must be 32 or 16                              */
+  int32_t bidir;           /* inter-chunk LSTM bidirectional (intra always is, dptn.py:59)      */
+  int32_t audio_only;      /* 1 -> DPTNWavEncDec (no video branch, no gate)                     */
+} dptnav_config;
+
+typedef struct dptnav_ctx* dptnav_handle;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int dptnav_abi_version(void);
+int dptnav_create(const dptnav_config* cfg, dptnav_handle* out);
+void dptnav_destroy(dptnav_handle h);
+/* last error of this handle (h may be NULL: error of the last failed dptnav_create). */
+const char* dptnav_last_error(dptnav_handle h);
+
+/* ---- weights: the caller keeps ownership (nn.Parameter storage) ------------------------- */
+/* The weight table has one slot per state_dict() tensor, in state_dict() order
+ * (228 slots for dptn_wav_av.yaml).  Names are the checkpoint keys. */
+int dptnav_num_weights(dptnav_handle h);
+const char* dptnav_weight_name(dptnav_handle h, int slot);
+int64_t dptnav_weight_numel(dptnav_handle h, int slot);
+/* Borrow n device pointers (fp32, contiguous, original PyTorch layouts).  May be called again
+ * whenever the parameters move (e.g. after .to(device) or load_state_dict).  No copies are made. */
+int dptnav_bind_weights(dptnav_handle h, const float* const* dev_ptrs, int n);
+
+/* ---- sizes ------------------------------------------------------------------------------ */
+int64_t dptnav_frames(dptnav_handle h, int64_t T);  /* L = (T-k)/stride + 1                    */
+int64_t dptnav_chunks(dptnav_handle h, int64_t T);  /* S = (L-K)/P + 1                         */
+size_t dptnav_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* replaces: DPTNAVWavEncDec.forward(mix, s1_embedding, s2_embedding, **batch) dptn_wav.py:171-194
+ *   mix      (B,T)            fp32     <- batch["mix"]
+ *   e1, e2   (B,Cv,Tv)        fp32     <- batch["s1_embedding"], batch["s2_embedding"] (NULL if audio_only)
+ *   s1_pred, s2_pred (B,T)    fp32     -> {"s1_pred","s2_pred"}
+ */
+int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T,
+                   int Tv, float* s1_pred, float* s2_pred, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---- stage entry points (the forward is exactly head -> 2*num_blocks paths -> tail) ------ */
+/* Token layout used between stages: x[b][s][k][n] (channel-last), i.e. the reference's
+ * (B,N,S,K) tensor permuted to (B,S,K,N) -- intra sequences are rows (b,s), inter sequences
+ * are strided views (b,k); no rearrange copies (dptn.py:71,74,77 do three per block).
+ *
+ * head: encoder conv + video fusion + chunking                 dptn_wav.py:172-184, dprnn.py:122-136
+ *   encoded (B,L,N) = fused latent (kept for the decoder skip, dptn_wav.py:188)
+ *   chunked (B,S,K,N) */
+int dptnav_stage_head(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T,
+                      int Tv, float* encoded, float* chunked, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* path: one TransformerDPRNN (dptn.py:36-52) of block `block`; path 0 = intra-chunk, 1 = inter-chunk.
+ *   x_in, x_out (B,S,K,N), must not alias. */
+int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* tail: PReLU + 1x1 conv + overlap-add + pad + postprocessing + skip + transposed conv + pad
+ *   dptn_wav.py:47-61, 186-193 */
+int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int B, int64_t T, float* s1_pred,
+                      float* s2_pred, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- introspection for tests / profiling ------------------------------------------------ */
+/* Offsets (in bytes, from the workspace base) of intermediates left behind by the LAST
+ * dptnav_stage_path call: "qkv" (M,3N), "att" (M,N), "y1" (M,N) [post-LN1], "hc" (M,2H)
+ * [ReLU(h_fwd|h_bwd)].  Returns non-zero for an unknown name. */
+int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* offset_bytes,
+                         size_t* numel);
+/* Algorithmic cost model used for roofline reporting. */
+double dptnav_flops_per_mixture(dptnav_handle h, int64_t T);
+double dptnav_min_bytes_per_mixture(dptnav_handle h, int64_t T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPTNAV_H_ */

@@ -1,0 +1,15 @@
+"""speech_separation_amd -- MI355X-native DPTN(-AV) separation forward path (libdptnav + thin host layer)."""
+from .spec import DPTN_AUDIO, DPTN_AV, DPTNConfig, state_dict_spec, synthetic_inputs, synthetic_state_dict
+
+__all__ = ["DPTNConfig", "DPTN_AV", "DPTN_AUDIO", "state_dict_spec", "synthetic_state_dict", "synthetic_inputs",
+           "DptnEngine", "DPTNAVWavEncDec", "DPTNWavEncDec"]
+
+
+def __getattr__(name):  # torch-dependent parts are imported lazily (spec.py stays numpy-only)
+    if name == "DptnEngine":
+        from .engine import DptnEngine
+        return DptnEngine
+    if name in ("DPTNAVWavEncDec", "DPTNWavEncDec"):
+        from . import model
+        return getattr(model, name)
+    raise AttributeError(name)

@@ -1,0 +1,135 @@
+// attention.h -- chunk-local multi-head self-attention for gfx950, exact fp32.
+//
+// Reference semantics: nn.MultiheadAttention(N, heads, batch_first=True) in eval mode, self-attention,
+// no mask (src/model/dptn.py:16-21,46): softmax(Q K^T / sqrt(dh)) V per head.  The in/out projections
+// are GEMM-engine launches; this kernel is the part between them.
+//
+// Sequences are short (K = 150 intra, S = 141 inter), so one workgroup = one (sequence, head) and the
+// whole score matrix lives in registers -- no online softmax.
+//   * NKB = ceil(len/32) waves; wave qb owns queries [32qb, 32qb+32).
+//   * K, V of the (sequence, head) are staged once in LDS (rows >= len are zero).
+//   * scores are computed TRANSPOSED: S^T[key][query] = K Q^T, so lane (c,hh) holds 16*NKB scores that
+//     all belong to query c -> the row max / row sum are register-local plus ONE cross-half shuffle.
+//   * P V: the accumulator register (rb, r) of S^T is used AS-IS as the MFMA A operand (k-slot hh means
+//     key rb*32 + ROW32(r,hh)); the B operand is the matching V row, read from LDS.  No transposes,
+//     no LDS round trip for P.
+//   * token addressing is strided (SeqGeom), so intra and inter views read the same QKV buffer.
+#pragma once
+#include "common.h"
+
+template <int DH>
+struct AttnShape {
+  static constexpr int LDK = DH + 4;  // K rows: conflict-free ds_read_b128
+  static constexpr int LDV = 32;      // V rows: 32 columns (zero padded when DH = 16)
+  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * (size_t)nkb * 32 * (LDK + LDV); }
+};
+
+template <int DH, int NKB>
+__global__ __launch_bounds__(64 * NKB) void attention_kernel(const float* __restrict__ qkv,
+                                                              float* __restrict__ out, int N, SeqGeom g,
+                                                              float scale_log2e) {
+  using Sh = AttnShape<DH>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                        // [NKB*32][LDK]
+  float* Vs = smem + NKB * 32 * Sh::LDK;   // [NKB*32][32]
+
+  const int tid = threadIdx.x;
+  const int qb = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int seq = blockIdx.x, head = blockIdx.y;
+  const int len = g.len;
+  const int64_t tok0 = seq_token_base(g, seq);
+  const int tstride = seq_token_stride(g);
+  const int ld = 3 * N;
+  const float* base = qkv + head * DH;
+
+  // ---- stage K and V ----------------------------------------------------------------------------
+  constexpr int R4 = DH / 4;  // float4 per row
+  for (int idx = tid; idx < NKB * 32 * R4; idx += 64 * NKB) {
+    const int p = idx / R4, f = idx % R4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (p < len) {
+      const float* row = base + (tok0 + (int64_t)p * tstride) * ld + 4 * f;
+      kv = *reinterpret_cast<const float4*>(row + N);
+      vv = *reinterpret_cast<const float4*>(row + 2 * N);
+    }
+    *reinterpret_cast<float4*>(&Ks[p * Sh::LDK + 4 * f]) = kv;
+    *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 4 * f]) = vv;
+    if (DH == 16) *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 16 + 4 * f]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- Q fragments (B operand), pre-scaled by log2(e)/sqrt(dh) ----------------------------------
+  float qf[DH / 2];
+  {
+    const int p = qb * 32 + c;
+    const float* row = base + (tok0 + (int64_t)(p < len ? p : 0) * tstride) * ld + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < DH / 8; ++m) {
+      float4 v = *reinterpret_cast<const float4*>(row + 8 * m);
+      if (p >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[4 * m + 0] = v.x * scale_log2e;
+      qf[4 * m + 1] = v.y * scale_log2e;
+      qf[4 * m + 2] = v.z * scale_log2e;
+      qf[4 * m + 3] = v.w * scale_log2e;
+    }
+  }
+  __syncthreads();
+
+  // ---- S^T = K Q^T ------------------------------------------------------------------------------
+  f32x16 s[NKB];
+#pragma unroll
+  for (int rb = 0; rb < NKB; ++rb) {
+    s[rb] = zero16();
+    const float* krow = &Ks[(rb * 32 + c) * Sh::LDK + 4 * hh];
+#pragma unroll
+    for (int m = 0; m < DH / 8; ++m) {
+      const float4 k = *reinterpret_cast<const float4*>(krow + 8 * m);
+      s[rb] = mfma32(k.x, qf[4 * m + 0], s[rb]);
+      s[rb] = mfma32(k.y, qf[4 * m + 1], s[rb]);
+      s[rb] = mfma32(k.z, qf[4 * m + 2], s[rb]);
+      s[rb] = mfma32(k.w, qf[4 * m + 3], s[rb]);
+    }
+  }
+
+  // ---- softmax over keys (per query = per lane column) ------------------------------------------
+  float mx = -1e30f;
+#pragma unroll
+  for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = rb * 32 + ROW32(r, hh);
+      const float v = key < len ? s[rb][r] : -1e30f;
+      s[rb][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = exp2f(s[rb][r] - mx);
+      s[rb][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+
+  // ---- O = P V ----------------------------------------------------------------------------------
+  f32x16 o = zero16();
+#pragma unroll
+  for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = Vs[(rb * 32 + ROW32(r, hh)) * Sh::LDV + c];
+      o = mfma32(s[rb][r], v, o);
+    }
+
+  // ---- normalise and store: reg r of lane (c,hh) is O[query ROW32(r,hh)][d = c] -----------------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ql = ROW32(r, hh);
+    const float iv = __shfl(inv, ql);  // lane ql holds the normaliser of query ql
+    const int p = qb * 32 + ql;
+    if (p < len && c < DH) out[(tok0 + (int64_t)p * tstride) * N + head * DH + c] = o[r] * iv;
+  }
+}

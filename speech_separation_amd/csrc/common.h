@@ -1,0 +1,74 @@
+// common.h -- shared device helpers for the gfx950 DPTN kernels.
+//
+// Conventions used by every kernel in this directory
+//   * wave = 64 lanes; c = lane & 31 ("column" lane), hh = lane >> 5 (half).
+//   * fp32 MFMA v_mfma_f32_32x32x2_f32:  D[i][j] += sum_{slot<2} A[i][slot] * B[slot][j]
+//       A operand: lane (i=c, slot=hh) supplies one float; B operand: lane (j=c, slot=hh).
+//       C/D: reg r of lane (c,hh) is element (row = ROW32(r,hh), col = c).
+//   * k-permutation: operands are fetched as float4 (16 B) so MFMA step s = 4m+t (t<4) uses the
+//     true k index 8m + 4hh + t for BOTH operands -- any bijection of k is a valid summation
+//     order as long as A and B agree.  This makes every fragment fetch a ds_read_b128 /
+//     global_load_dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DEV __device__ __forceinline__
+
+// row index of accumulator register r (0..15) for half hh in a 32x32 tile
+#define ROW32(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
+
+DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+DEV f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+DEV float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// 2/(1+e^-2x) - 1 : saturates correctly to +-1 (no inf/inf)
+DEV float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// Sequence geometry of one TransformerDPRNN call over the token tensor x[b][s][k][n].
+//   mode 0 (intra-chunk): sequence q = b*S + s, position t = k   -> token q*K + t
+//   mode 1 (inter-chunk): sequence q = b*K + k, position t = s   -> token (b*S + t)*K + k
+struct SeqGeom {
+  int mode;
+  int B, S, K;
+  int nseq;  // B*S or B*K
+  int len;   // K or S
+  int nst;   // ceil(nseq/32) sequence tiles
+};
+
+DEV int64_t seq_token_base(const SeqGeom& g, int q) {
+  if (g.mode == 0) return (int64_t)q * g.K;
+  int b = q / g.K, k = q - b * g.K;
+  return (int64_t)b * g.S * g.K + k;
+}
+DEV int seq_token_stride(const SeqGeom& g) { return g.mode == 0 ? 1 : g.K; }
+
+static inline SeqGeom make_geom(int mode, int B, int S, int K) {
+  SeqGeom g;
+  g.mode = mode;
+  g.B = B;
+  g.S = S;
+  g.K = K;
+  g.nseq = mode == 0 ? B * S : B * K;
+  g.len = mode == 0 ? K : S;
+  g.nst = (g.nseq + 31) / 32;
+  return g;
+}
+
+// Pre-activation (x W_ih^T + b) layout consumed by the LSTM kernel, in floats:
+//   PRE[d][st][t][cb(16)][q(4)][hh(2)][c(32)][i(4)]
+// where for direction d, sequence tile st, position t: gate column j = cb*32 + c (j = g*H + u),
+// tile row rho = 8q + 4hh + i.  A lane's four consecutive accumulator registers 4q..4q+3 are one
+// float4, and one wave instruction moves 1 KiB contiguously.
+DEV int64_t pre_tile_offset(int d, int st, int t, int nst, int len) {
+  return (((int64_t)d * nst + st) * len + t) * (int64_t)(512 * 32);
+}

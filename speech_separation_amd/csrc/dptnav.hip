@@ -1,0 +1,562 @@
+// dptnav.hip -- host side of libdptnav.so: handle, weight table, workspace plan, launch sequence and
+// the extern "C" boundary declared in include/dptnav.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dptnav.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm_ws.h"
+#include "headtail.h"
+#include "lstm.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct PathWeights {
+  const float *in_w, *in_b, *out_w, *out_b, *ln1_w, *ln1_b;
+  const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
+  const float *ffn_w, *ffn_b, *ln2_w, *ln2_b;
+  int ndir;
+};
+
+struct Plan {  // workspace offsets in floats
+  int64_t L, S, M;
+  size_t vid, E, X0, X1, qkv, att, y1, pre, hc, total;
+  size_t qkv_n, att_n, y1_n, hc_n;
+};
+
+}  // namespace
+
+struct dptnav_ctx {
+  dptnav_config cfg;
+  std::vector<std::string> names;
+  std::vector<int64_t> numel;
+  std::vector<const float*> ptr;
+  bool bound = false;
+  std::string err;
+  int stride;
+  int dh;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  int slot(const std::string& n) const {
+    for (size_t i = 0; i < names.size(); ++i)
+      if (names[i] == n) return (int)i;
+    return -1;
+  }
+  const float* w(const std::string& n) const { return ptr[slot(n)]; }
+};
+
+namespace {
+
+inline size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
+
+void build_names(dptnav_ctx* c) {
+  const dptnav_config& g = c->cfg;
+  const int64_t N = g.num_features, H = g.hidden_dim, k = g.kernel_size_enc;
+  auto add = [&](const std::string& n, int64_t e) {
+    c->names.push_back(n);
+    c->numel.push_back(e);
+  };
+  if (!g.audio_only) add("gate", 1);
+  add("encoder.weight", N * k);
+  if (!g.audio_only) {
+    add("visual_compression.weight", (int64_t)(g.hidden_video / 2) * g.video_emb_size);
+    add("visual_compression.bias", g.hidden_video / 2);
+    add("video_ln.weight", g.hidden_video);
+    add("video_ln.bias", g.hidden_video);
+  }
+  for (int b = 0; b < g.num_blocks; ++b)
+    for (int p = 0; p < 2; ++p) {
+      const std::string pre =
+          "dprnn.model." + std::to_string(b) + (p == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
+      const int ndir = (p == 0 || g.bidir) ? 2 : 1;
+      add(pre + "mha.in_proj_weight", 3 * N * N);
+      add(pre + "mha.in_proj_bias", 3 * N);
+      add(pre + "mha.out_proj.weight", N * N);
+      add(pre + "mha.out_proj.bias", N);
+      add(pre + "ln1.weight", N);
+      add(pre + "ln1.bias", N);
+      add(pre + "rnn.weight_ih_l0", 4 * H * N);
+      add(pre + "rnn.weight_hh_l0", 4 * H * H);
+      add(pre + "rnn.bias_ih_l0", 4 * H);
+      add(pre + "rnn.bias_hh_l0", 4 * H);
+      if (ndir == 2) {
+        add(pre + "rnn.weight_ih_l0_reverse", 4 * H * N);
+        add(pre + "rnn.weight_hh_l0_reverse", 4 * H * H);
+        add(pre + "rnn.bias_ih_l0_reverse", 4 * H);
+        add(pre + "rnn.bias_hh_l0_reverse", 4 * H);
+      }
+      add(pre + "ffn.1.weight", N * H * ndir);
+      add(pre + "ffn.1.bias", N);
+      add(pre + "ln2.weight", N);
+      add(pre + "ln2.bias", N);
+    }
+  add("dprnn.speakers_separation.0.weight", 1);
+  add("dprnn.speakers_separation.1.weight", 2 * N * N);
+  add("dprnn.speakers_separation.1.bias", 2 * N);
+  add("dprnn.postprocessing.0.weight", N * N);
+  add("dprnn.postprocessing.0.bias", N);
+  add("decoder.weight", N * k);
+  c->ptr.assign(c->names.size(), nullptr);
+}
+
+PathWeights path_weights(const dptnav_ctx* c, int block, int path) {
+  const std::string pre =
+      "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
+  PathWeights p{};
+  p.ndir = (path == 0 || c->cfg.bidir) ? 2 : 1;
+  p.in_w = c->w(pre + "mha.in_proj_weight");
+  p.in_b = c->w(pre + "mha.in_proj_bias");
+  p.out_w = c->w(pre + "mha.out_proj.weight");
+  p.out_b = c->w(pre + "mha.out_proj.bias");
+  p.ln1_w = c->w(pre + "ln1.weight");
+  p.ln1_b = c->w(pre + "ln1.bias");
+  p.w_ih[0] = c->w(pre + "rnn.weight_ih_l0");
+  p.w_hh[0] = c->w(pre + "rnn.weight_hh_l0");
+  p.b_ih[0] = c->w(pre + "rnn.bias_ih_l0");
+  p.b_hh[0] = c->w(pre + "rnn.bias_hh_l0");
+  if (p.ndir == 2) {
+    p.w_ih[1] = c->w(pre + "rnn.weight_ih_l0_reverse");
+    p.w_hh[1] = c->w(pre + "rnn.weight_hh_l0_reverse");
+    p.b_ih[1] = c->w(pre + "rnn.bias_ih_l0_reverse");
+    p.b_hh[1] = c->w(pre + "rnn.bias_hh_l0_reverse");
+  } else {
+    p.w_ih[1] = p.w_ih[0];
+    p.w_hh[1] = p.w_hh[0];
+    p.b_ih[1] = p.b_ih[0];
+    p.b_hh[1] = p.b_hh[0];
+  }
+  p.ffn_w = c->w(pre + "ffn.1.weight");
+  p.ffn_b = c->w(pre + "ffn.1.bias");
+  p.ln2_w = c->w(pre + "ln2.weight");
+  p.ln2_b = c->w(pre + "ln2.bias");
+  return p;
+}
+
+int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
+  const dptnav_config& g = c->cfg;
+  if (B <= 0 || T < g.kernel_size_enc) return c->fail(DPTNAV_ERR_INVALID, "bad shape B=%d T=%lld", B, (long long)T);
+  const int64_t N = g.num_features, H = g.hidden_dim;
+  p->L = (T - g.kernel_size_enc) / c->stride + 1;
+  if (p->L < g.chunk_size)
+    return c->fail(DPTNAV_ERR_INVALID, "T=%lld gives L=%lld frames < chunk_size=%d", (long long)T, (long long)p->L,
+                   g.chunk_size);
+  p->S = (p->L - g.chunk_size) / g.step_size + 1;
+  if (p->S > 256 || g.chunk_size > 256)
+    return c->fail(DPTNAV_ERR_INVALID, "sequence length > 256 unsupported by the attention kernel (S=%lld, K=%d)",
+                   (long long)p->S, g.chunk_size);
+  if ((int64_t)B * p->S * g.chunk_size * 3 * N >= ((int64_t)1 << 31))
+    return c->fail(DPTNAV_ERR_INVALID, "batch too large for 32-bit token indexing (B=%d)", B);
+  p->M = (int64_t)B * p->S * g.chunk_size;
+  const int64_t nst_a = ((int64_t)B * p->S + 31) / 32, nst_e = ((int64_t)B * g.chunk_size + 31) / 32;
+  const int64_t pre_tiles = std::max(nst_a * g.chunk_size, nst_e * p->S);
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t at = o;
+    o += align64(n);
+    return at;
+  };
+  p->vid = take((size_t)B * (Tv > 0 ? Tv : 1) * N);
+  p->E = take((size_t)B * p->L * N);
+  p->X0 = take((size_t)p->M * N);
+  p->X1 = take((size_t)p->M * N);
+  p->qkv_n = (size_t)p->M * 3 * N;
+  p->qkv = take(p->qkv_n);
+  p->att_n = (size_t)p->M * N;
+  p->att = take(std::max(p->att_n, (size_t)2 * B * p->L * 8));
+  p->y1_n = (size_t)p->M * N;
+  p->y1 = take(p->y1_n);
+  p->pre = take((size_t)2 * pre_tiles * 512 * 32);
+  p->hc_n = (size_t)p->M * 2 * H;
+  p->hc = take(p->hc_n);
+  p->total = o;
+  return DPTNAV_OK;
+}
+
+#define LAUNCH_CHECK(c, what)                                                                  \
+  do {                                                                                          \
+    hipError_t e_ = hipGetLastError();                                                          \
+    if (e_ != hipSuccess) return (c)->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class Kern>
+int set_lds(dptnav_ctx* c, Kern kern, size_t bytes, const char* what) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "%s: set LDS %zu: %s", what, bytes, hipGetErrorString(e));
+  }
+  return DPTNAV_OK;
+}
+
+inline int cap_grid(int64_t ntiles, int cap) { return (int)(ntiles < cap ? ntiles : cap); }
+
+// ---- attention dispatch over the number of 32-key blocks ----------------------------------------
+template <int DH, int NKB>
+int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads,
+                    hipStream_t st) {
+  auto kern = attention_kernel<DH, NKB>;
+  const size_t lds = AttnShape<DH>::lds_bytes(NKB);
+  if (int rc = set_lds(c, kern, lds, "attention")) return rc;
+  const float scale = 1.4426950408889634f / sqrtf((float)DH);
+  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale);
+  LAUNCH_CHECK(c, "attention");
+  return DPTNAV_OK;
+}
+template <int DH>
+int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads, hipStream_t st) {
+  switch ((g.len + 31) / 32) {
+    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st);
+    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st);
+    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st);
+    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st);
+    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st);
+    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st);
+    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st);
+    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st);
+  }
+  return c->fail(DPTNAV_ERR_INVALID, "attention: sequence length %d > 256", g.len);
+}
+
+// ---- generic GEMM-engine launch -------------------------------------------------------------------
+template <int KIN, int NT, int WR, int WC, class AL, class EP>
+int launch_gemm(dptnav_ctx* c, const char* what, const float* W, int64_t ntiles, int colgroups, int cap,
+                const AL& al, const EP& ep, hipStream_t st, const float* Walt = nullptr) {
+  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP>;
+  const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
+  if (int rc = set_lds(c, kern, lds, what)) return rc;
+  hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, cap), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
+                     al, ep);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
+// ---- one TransformerDPRNN (dptn.py:36-52) ---------------------------------------------------------
+template <int N>
+int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out, int B, int S, float* ws,
+             const Plan& pl, hipStream_t st) {
+  constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4, DH = N / 4;
+  constexpr int BM = 32 * WR;
+  const dptnav_config& g = c->cfg;
+  const PathWeights w = path_weights(c, block, path);
+  const int K = g.chunk_size;
+  const int64_t M = (int64_t)B * S * K;
+  const SeqGeom geom = make_geom(path, B, S, K);
+  float *qkv = ws + pl.qkv, *att = ws + pl.att, *y1 = ws + pl.y1, *pre = ws + pl.pre, *hc = ws + pl.hc;
+  const int64_t ntiles = (M + BM - 1) / BM;
+
+  // K1: qkv = x W_in^T + b_in                                  (nn.MultiheadAttention in-projection)
+  {
+    ALoadDense al{x_in, M, N, BM};
+    EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
+    if (int rc = launch_gemm<N, 3, WR, WC>(c, "qkv gemm", w.in_w, ntiles, 1, 512, al, ep, st)) return rc;
+  }
+  // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
+  if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
+  // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
+  {
+    ALoadDense al{att, M, N, BM};
+    EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, "out-proj gemm", w.out_w, ntiles, 1, 1024, al, ep, st)) return rc;
+  }
+  // K4: LSTM pre-activations for every (direction, sequence tile, position)
+  {
+    ALoadSeqTile al{y1, N, geom};
+    EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
+    const int64_t nt4 = (int64_t)geom.nst * geom.len;
+    if (int rc = launch_gemm<N, 4, 1, 4>(c, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, 512, al, ep, st, w.w_ih[1]))
+      return rc;
+  }
+  // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
+  {
+    if (int rc = set_lds(c, lstm_recurrence_kernel, LSTM_LDS_BYTES, "lstm")) return rc;
+    hipLaunchKernelGGL(lstm_recurrence_kernel, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0],
+                       w.w_hh[1], hc, w.ndir * LSTM_H, geom);
+    LAUNCH_CHECK(c, "lstm");
+  }
+  // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
+  {
+    EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
+    if (w.ndir == 2) {
+      ALoadDense al{hc, M, 2 * LSTM_H, BM};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+    } else {
+      ALoadDense al{hc, M, LSTM_H, BM};
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+    }
+  }
+  return DPTNAV_OK;
+}
+
+template <int N>
+int run_head(dptnav_ctx* c, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+             float* E, float* X, float* ws, const Plan& pl, hipStream_t st) {
+  const dptnav_config& g = c->cfg;
+  const float* vid = nullptr;
+  if (!g.audio_only) {
+    float* v = ws + pl.vid;
+    hipLaunchKernelGGL(video_linear_kernel, dim3(B, 2), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
+                       c->w("visual_compression.bias"), v, g.video_emb_size, Tv, g.hidden_video / 2);
+    LAUNCH_CHECK(c, "video linear");
+    vid = v;
+  }
+  constexpr int FPB = 256 / (N / 4);
+  hipLaunchKernelGGL(encoder_fuse_kernel<N>, dim3((unsigned)((pl.L + FPB - 1) / FPB), B), dim3(256), 0, st, mix,
+                     c->w("encoder.weight"), vid, g.audio_only ? nullptr : c->w("gate"),
+                     g.audio_only ? nullptr : c->w("video_ln.weight"), g.audio_only ? nullptr : c->w("video_ln.bias"),
+                     E, X, T, (int)pl.L, g.kernel_size_enc, c->stride, Tv, (int)pl.S, g.chunk_size, g.step_size);
+  LAUNCH_CHECK(c, "encoder+fusion");
+  return DPTNAV_OK;
+}
+
+template <int N>
+int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, float* s1, float* s2, float* ws,
+             const Plan& pl, hipStream_t st) {
+  constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4;
+  constexpr int BM = 32 * WR;
+  const dptnav_config& g = c->cfg;
+  float *Z = ws + pl.qkv, *D = ws + pl.att;
+  const int64_t M = pl.M;
+  // T1: Z = PReLU(x) W_sep^T + b_sep                            (dptn_wav.py:26-29,47)
+  {
+    ALoadDensePReLU al{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
+    EpiBiasStore ep{Z, c->w("dprnn.speakers_separation.1.bias"), M, 2 * N, 32, 2 * N};
+    if (int rc = launch_gemm<N, N / 64, 1, 4>(c, "separation gemm", c->w("dprnn.speakers_separation.1.weight"),
+                                              (M + 31) / 32, 1, 1024, al, ep, st))
+      return rc;
+  }
+  // T2: overlap-add gather -> post-processing conv -> + E -> decoder tap products
+  const int ola = (int)((pl.S - 1) * g.step_size + g.chunk_size);
+  const int left = (int)((pl.L - ola) / 2);
+  {
+    const int64_t rows = (int64_t)2 * B * pl.L;
+    ALoadOla al{Z, N, B, (int)pl.L, (int)pl.S, g.chunk_size, g.step_size, left, ola, BM};
+    EpiSkipDecoderTaps<GROUP> ep{D, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"),
+                                 (int64_t)B * pl.L, g.kernel_size_enc, BM};
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, "postproc gemm", c->w("dprnn.postprocessing.0.weight"),
+                                           (rows + BM - 1) / BM, 1, 1024, al, ep, st))
+      return rc;
+  }
+  // T3: transposed-conv gather + zero padding
+  {
+    const int64_t ndec = (pl.L - 1) * c->stride + g.kernel_size_enc;
+    const int pad_left = (int)((T - ndec) / 2);
+    hipLaunchKernelGGL(decoder_gather_kernel, dim3((unsigned)((T + 255) / 256), B, 2), dim3(256), 0, st, D, s1, s2, B,
+                       T, (int)pl.L, g.kernel_size_enc, c->stride, pad_left);
+    LAUNCH_CHECK(c, "decoder gather");
+  }
+  return DPTNAV_OK;
+}
+
+int check_common(dptnav_ctx* c, int B, int64_t T, int Tv, void* ws, size_t ws_bytes, Plan* pl) {
+  if (!c->bound) return c->fail(DPTNAV_ERR_WEIGHTS, "weights not bound: call dptnav_bind_weights first");
+  if (int rc = make_plan(c, B, T, Tv, pl)) return rc;
+  if (ws == nullptr || ((uintptr_t)ws & 255) != 0)
+    return c->fail(DPTNAV_ERR_WORKSPACE, "workspace must be non-null and 256-byte aligned");
+  if (ws_bytes < pl->total * sizeof(float))
+    return c->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, pl->total * sizeof(float));
+  return DPTNAV_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int dptnav_abi_version(void) { return DPTNAV_ABI_VERSION; }
+
+const char* dptnav_last_error(dptnav_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dptnav_create(const dptnav_config* cfg, dptnav_handle* out) {
+  auto bad = [&](const char* m) {
+    g_create_error = m;
+    return DPTNAV_ERR_INVALID;
+  };
+  if (!cfg || !out) return bad("null argument");
+  *out = nullptr;
+  if (cfg->num_features != 128 && cfg->num_features != 64) return bad("num_features must be 128 or 64");
+  if (cfg->hidden_dim != 128) return bad("hidden_dim must be 128");
+  if (cfg->num_heads != 4) return bad("num_heads must be 4 (head dim 32 or 16)");
+  if (cfg->kernel_size_enc < 2 || cfg->kernel_size_enc > 8) return bad("kernel_size_enc must be in [2,8]");
+  if (cfg->num_blocks < 1) return bad("num_blocks must be >= 1");
+  if (cfg->chunk_size < 1 || cfg->chunk_size > 256) return bad("chunk_size must be in [1,256]");
+  if (cfg->step_size < 1 || cfg->step_size > cfg->chunk_size) return bad("step_size must be in [1,chunk_size]");
+  if (!cfg->audio_only) {
+    if (cfg->hidden_video != cfg->num_features) return bad("hidden_video must equal num_features");
+    if (cfg->video_emb_size < 1) return bad("video_emb_size must be >= 1");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return bad("no HIP device visible: libdptnav has no CPU path");
+  dptnav_ctx* c = new dptnav_ctx();
+  c->cfg = *cfg;
+  c->stride = cfg->kernel_size_enc / 2;
+  c->dh = cfg->num_features / cfg->num_heads;
+  build_names(c);
+  *out = c;
+  return DPTNAV_OK;
+}
+
+void dptnav_destroy(dptnav_handle h) { delete h; }
+
+int dptnav_num_weights(dptnav_handle h) { return h ? (int)h->names.size() : 0; }
+const char* dptnav_weight_name(dptnav_handle h, int s) {
+  return (h && s >= 0 && s < (int)h->names.size()) ? h->names[s].c_str() : nullptr;
+}
+int64_t dptnav_weight_numel(dptnav_handle h, int s) {
+  return (h && s >= 0 && s < (int)h->numel.size()) ? h->numel[s] : -1;
+}
+
+int dptnav_bind_weights(dptnav_handle h, const float* const* dev_ptrs, int n) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!dev_ptrs || n != (int)h->names.size())
+    return h->fail(DPTNAV_ERR_WEIGHTS, "expected %zu weight pointers, got %d", h->names.size(), n);
+  for (int i = 0; i < n; ++i) {
+    if (dev_ptrs[i] == nullptr) return h->fail(DPTNAV_ERR_WEIGHTS, "null pointer for %s", h->names[i].c_str());
+    if (((uintptr_t)dev_ptrs[i] & 15) != 0)
+      return h->fail(DPTNAV_ERR_WEIGHTS, "%s is not 16-byte aligned", h->names[i].c_str());
+  }
+  h->ptr.assign(dev_ptrs, dev_ptrs + n);
+  h->bound = true;
+  return DPTNAV_OK;
+}
+
+int64_t dptnav_frames(dptnav_handle h, int64_t T) {
+  return h ? (T - h->cfg.kernel_size_enc) / h->stride + 1 : -1;
+}
+int64_t dptnav_chunks(dptnav_handle h, int64_t T) {
+  return h ? (dptnav_frames(h, T) - h->cfg.chunk_size) / h->cfg.step_size + 1 : -1;
+}
+
+size_t dptnav_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
+  if (!h) return 0;
+  Plan pl;
+  if (make_plan(h, B, T, Tv, &pl)) return 0;
+  return pl.total * sizeof(float);
+}
+
+int dptnav_stage_head(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+                      float* encoded, float* chunked, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  Plan pl;
+  if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
+  if (!mix || !encoded || !chunked || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1)))
+    return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  hipStream_t st = (hipStream_t)stream;
+  return h->cfg.num_features == 128 ? run_head<128>(h, mix, e1, e2, B, T, Tv, encoded, chunked, (float*)ws, pl, st)
+                                    : run_head<64>(h, mix, e1, e2, B, T, Tv, encoded, chunked, (float*)ws, pl, st);
+}
+
+int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S, void* ws,
+                      size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1))
+    return h->fail(DPTNAV_ERR_INVALID, "bad block/path %d/%d", block, path);
+  if (!x_in || !x_out || x_in == x_out) return h->fail(DPTNAV_ERR_INVALID, "x_in/x_out null or aliased");
+  if (S < 1 || S > 256) return h->fail(DPTNAV_ERR_INVALID, "S=%d out of range", S);
+  // a T that yields exactly S chunks
+  const int64_t L = (int64_t)(S - 1) * h->cfg.step_size + h->cfg.chunk_size;
+  const int64_t T = (L - 1) * h->stride + h->cfg.kernel_size_enc;
+  Plan pl;
+  if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  return h->cfg.num_features == 128 ? run_path<128>(h, block, path, x_in, x_out, B, S, (float*)ws, pl, st)
+                                    : run_path<64>(h, block, path, x_in, x_out, B, S, (float*)ws, pl, st);
+}
+
+int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int B, int64_t T, float* s1, float* s2,
+                      void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  Plan pl;
+  if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
+  if (!x || !encoded || !s1 || !s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  hipStream_t st = (hipStream_t)stream;
+  return h->cfg.num_features == 128 ? run_tail<128>(h, x, encoded, B, T, s1, s2, (float*)ws, pl, st)
+                                    : run_tail<64>(h, x, encoded, B, T, s1, s2, (float*)ws, pl, st);
+}
+
+int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+                   float* s1, float* s2, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  Plan pl;
+  if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
+  if (!mix || !s1 || !s2 || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1)))
+    return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  hipStream_t st = (hipStream_t)stream;
+  float* w = (float*)ws;
+  float *E = w + pl.E, *X0 = w + pl.X0, *X1 = w + pl.X1;
+  const bool big = h->cfg.num_features == 128;
+  int rc = big ? run_head<128>(h, mix, e1, e2, B, T, Tv, E, X0, w, pl, st)
+               : run_head<64>(h, mix, e1, e2, B, T, Tv, E, X0, w, pl, st);
+  if (rc) return rc;
+  for (int b = 0; b < h->cfg.num_blocks; ++b) {
+    rc = big ? run_path<128>(h, b, 0, X0, X1, B, (int)pl.S, w, pl, st)
+             : run_path<64>(h, b, 0, X0, X1, B, (int)pl.S, w, pl, st);
+    if (rc) return rc;
+    rc = big ? run_path<128>(h, b, 1, X1, X0, B, (int)pl.S, w, pl, st)
+             : run_path<64>(h, b, 1, X1, X0, B, (int)pl.S, w, pl, st);
+    if (rc) return rc;
+  }
+  return big ? run_tail<128>(h, X0, E, B, T, s1, s2, w, pl, st) : run_tail<64>(h, X0, E, B, T, s1, s2, w, pl, st);
+}
+
+int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* off, size_t* numel) {
+  if (!h || !name || !off || !numel) return DPTNAV_ERR_INVALID;
+  Plan pl;
+  if (int rc = make_plan(h, B, T, Tv, &pl)) return rc;
+  const std::string n(name);
+  if (n == "qkv") { *off = pl.qkv * 4; *numel = pl.qkv_n; }
+  else if (n == "att") { *off = pl.att * 4; *numel = pl.att_n; }
+  else if (n == "y1") { *off = pl.y1 * 4; *numel = pl.y1_n; }
+  else if (n == "hc") { *off = pl.hc * 4; *numel = pl.hc_n; }
+  else if (n == "encoded") { *off = pl.E * 4; *numel = (size_t)B * pl.L * h->cfg.num_features; }
+  else return h->fail(DPTNAV_ERR_INVALID, "unknown tap '%s'", name);
+  return DPTNAV_OK;
+}
+
+// Algorithmic cost model (2 FLOP per MAC, GEMM-like terms only) -- SURVEY.md section 8d restated.
+double dptnav_flops_per_mixture(dptnav_handle h, int64_t T) {
+  if (!h) return 0;
+  const dptnav_config& g = h->cfg;
+  const double N = g.num_features, H = g.hidden_dim, K = g.chunk_size;
+  const double L = (double)dptnav_frames(h, T), S = (double)dptnav_chunks(h, T), M = S * K;
+  auto path = [&](double len, double ndir) {
+    return 2 * N * 3 * N + 2 * N * N + 4 * len * N + ndir * (2 * N * 4 * H + 2 * H * 4 * H) + 2 * ndir * H * N;
+  };
+  double f = g.num_blocks * M * (path(K, 2) + path(S, g.bidir ? 2 : 1));
+  f += 2 * N * 2 * N * M;                 // separation conv
+  f += 2 * 2 * N * N * L;                 // post-processing conv, both speakers
+  f += 2 * N * g.kernel_size_enc * L;     // encoder
+  f += 2 * 2 * N * g.kernel_size_enc * L; // decoder
+  if (!g.audio_only) f += 2.0 * 2 * 50 * g.video_emb_size * (g.hidden_video / 2);
+  return f;
+}
+
+// Ideal-fusion HBM traffic: every TransformerDPRNN reads x once and writes y once.
+double dptnav_min_bytes_per_mixture(dptnav_handle h, int64_t T) {
+  if (!h) return 0;
+  const dptnav_config& g = h->cfg;
+  const double N = g.num_features, K = g.chunk_size;
+  const double L = (double)dptnav_frames(h, T), S = (double)dptnav_chunks(h, T), M = S * K;
+  const double A = M * N * 4, F = L * N * 4;
+  return g.num_blocks * 2 * 2 * A + (A + 2 * 2 * A) + 2 * 2 * F + 4 * F + F + 3.0 * T * 4;
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+// gemm_ws.h -- "weights-stationary" fp32 MFMA GEMM engine for gfx950.
+//
+// Every dense contraction on the DPTN path is   out[M, NOUT] = f(A[M, KIN]) * W[NOUT, KIN]^T   with a
+// HUGE M (B*S*K ~ 3.4e5 tokens) and TINY weights (<= 1024 x 256 fp32).  So the tiling is turned
+// inside out relative to a square GEMM: a workgroup loads its slice of W ONCE into registers as
+// ready-made MFMA B-fragments (the 512 KiB register file of a CU is the biggest on-chip memory)
+// and then streams 32-row token tiles through LDS, persistent-style.
+//
+//   block = 256 threads = WR x WC waves; wave (wr, wc) owns rows [32wr, 32wr+32) of the BM = 32*WR row
+//   tile and columns col0 + (wc*NT + nt)*32 + c, nt < NT.
+//
+// Template hooks
+//   ALoad::load4(tile, row, k4)      -> float4 of A for tile row `row` (0..BM-1), floats [4*k4, 4*k4+4)
+//                                       (gather / prologue ops such as PReLU live here)
+//   Epi::DIRECT == true : Epi::store_acc(tile, wr, cb, acc, c, hh)   register epilogue (LSTM pre-acts)
+//   Epi::DIRECT == false: Epi::row(tile, row, c4, float4 v)          row-space epilogue: the C tile goes
+//                          through LDS, a row of the tile is handled by GROUP = WGCOLS/4 adjacent lanes
+//                          (so LayerNorm statistics are a sub-wave shuffle reduction).
+#pragma once
+#include "common.h"
+
+template <int KIN, int NT, int WR, int WC>
+struct GemmShape {
+  static constexpr int BM = 32 * WR;
+  static constexpr int WGCOLS = 32 * NT * WC;
+  static constexpr int LDA = KIN + 4;      // +4 floats: conflict-free ds_read_b128 fragments
+  static constexpr int LDC = WGCOLS + 4;
+  static constexpr int KS = KIN / 2;       // MFMA k-steps
+  static constexpr size_t lds_bytes(bool direct) {
+    return sizeof(float) * ((size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
+  }
+};
+
+template <int KIN, int NT, int WR, int WC, class ALoad, class Epi>
+__global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ W,
+                                                       const float* __restrict__ Walt, int ldw, int ntiles,
+                                                       ALoad aload, Epi epi) {
+  using Sh = GemmShape<KIN, NT, WR, WC>;
+  static_assert(WR * WC == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Cs = smem + Sh::BM * Sh::LDA;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+  const int colgroup = blockIdx.y;  // which WGCOLS-wide slice of NOUT
+
+  // ---- weights -> B fragments, once ----------------------------------------------------------
+  // (Walt != null: column group 1 reads a second weight tensor, e.g. the reverse-direction W_ih)
+  const float* Wsel = (Walt != nullptr && colgroup == 1) ? Walt : W;
+  const int jbase = Walt != nullptr ? 0 : colgroup * Sh::WGCOLS;
+  float wf[NT][Sh::KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int j = jbase + (wc * NT + nt) * 32 + c;
+    const float* wrow = Wsel + (int64_t)j * ldw + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < KIN / 8; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * m);
+      wf[nt][4 * m + 0] = v.x;
+      wf[nt][4 * m + 1] = v.y;
+      wf[nt][4 * m + 2] = v.z;
+      wf[nt][4 * m + 3] = v.w;
+    }
+  }
+
+  constexpr int K4 = KIN / 4;                       // float4 per A row
+  constexpr int NLD = (Sh::BM * K4) / 256;          // float4 loads per thread per tile
+  static_assert((Sh::BM * K4) % 256 == 0, "tile/threads");
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- stage the A tile (coalesced: consecutive lanes = consecutive float4 of a row) --------
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = i * 256 + tid;
+      const int row = idx / K4, k4 = idx % K4;
+      const float4 v = aload.load4(tile, row, k4);
+      *reinterpret_cast<float4*>(&As[row * Sh::LDA + 4 * k4]) = v;
+    }
+    __syncthreads();
+
+    // ---- A fragments + MFMA --------------------------------------------------------------------
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    {
+      const float* arow = &As[(wr * 32 + c) * Sh::LDA + 4 * hh];
+#pragma unroll
+      for (int m = 0; m < KIN / 8; ++m) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[nt] = mfma32(a.x, wf[nt][4 * m + 0], acc[nt]);
+          acc[nt] = mfma32(a.y, wf[nt][4 * m + 1], acc[nt]);
+          acc[nt] = mfma32(a.z, wf[nt][4 * m + 2], acc[nt]);
+          acc[nt] = mfma32(a.w, wf[nt][4 * m + 3], acc[nt]);
+        }
+      }
+    }
+
+    if constexpr (Epi::DIRECT) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
+      __syncthreads();  // As is rewritten by the next tile
+    } else {
+      // ---- C tile -> LDS (each half-wave writes 128 B contiguous), then row-space epilogue ------
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = (wc * NT + nt) * 32 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[(wr * 32 + ROW32(r, hh)) * Sh::LDC + col] = acc[nt][r];
+      }
+      __syncthreads();
+      constexpr int C4 = Sh::WGCOLS / 4;              // float4 per C row
+      constexpr int NPASS = (Sh::BM * C4) / 256;
+      static_assert((Sh::BM * C4) % 256 == 0, "epilogue mapping");
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int idx = p * 256 + tid;
+        const int row = idx / C4, c4 = idx % C4;
+        const float4 v = *reinterpret_cast<const float4*>(&Cs[row * Sh::LDC + 4 * c4]);
+        epi.row(tile, row, colgroup, c4, v);
+      }
+      // next iteration's first barrier orders these Cs reads before the next Cs writes; As is
+      // only rewritten after every wave passed the barrier above (fragments already in registers)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A loaders
+// ------------------------------------------------------------------------------------------------
+// rows are consecutive tokens of a dense [M][lda] matrix
+struct ALoadDense {
+  const float* A;
+  int64_t M;
+  int lda;
+  int bm;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(A + r * lda + 4 * k4);
+  }
+};
+
+// dense rows with PReLU applied on the fly (dptn_wav.py:27 -- single shared slope)
+struct ALoadDensePReLU {
+  const float* A;
+  const float* slope;
+  int64_t M;
+  int lda;
+  int bm;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(A + r * lda + 4 * k4);
+    const float a = *slope;
+    v.x = v.x >= 0.f ? v.x : a * v.x;
+    v.y = v.y >= 0.f ? v.y : a * v.y;
+    v.z = v.z >= 0.f ? v.z : a * v.z;
+    v.w = v.w >= 0.f ? v.w : a * v.w;
+    return v;
+  }
+};
+
+// tile = (sequence tile st, position t): the 32 rows are the 32 sequences of tile st at position t
+struct ALoadSeqTile {
+  const float* A;  // token-major [M][lda]
+  int lda;
+  SeqGeom g;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int st = tile / g.len, t = tile - st * g.len;
+    const int q = st * 32 + row;
+    if (q >= g.nseq) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t tok = seq_token_base(g, q) + (int64_t)t * seq_token_stride(g);
+    return *reinterpret_cast<const float4*>(A + tok * lda + 4 * k4);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// epilogues
+// ------------------------------------------------------------------------------------------------
+// out[row][colgroup*WGCOLS + 4*c4 ..] = v + bias
+struct EpiBiasStore {
+  static constexpr bool DIRECT = false;
+  float* out;
+  const float* bias;
+  int64_t M;
+  int ldo;
+  int bm;
+  int wgcols;
+  DEV void row(int tile, int row, int colgroup, int c4, float4 v) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return;
+    const int col = colgroup * wgcols + 4 * c4;
+    const float4 b = *reinterpret_cast<const float4*>(bias + col);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    *reinterpret_cast<float4*>(out + r * ldo + col) = v;
+  }
+};
+
+// y = LayerNorm(v + bias + residual) over the NCOL = 4*GROUP columns of the row (dptn.py:46-47, 50-51)
+template <int GROUP>
+struct EpiBiasResLN {
+  static constexpr bool DIRECT = false;
+  float* out;
+  const float* bias;
+  const float* res;    // [M][ld]
+  const float* gamma;
+  const float* beta;
+  int64_t M;
+  int ld;
+  int bm;
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    const bool ok = r < M;
+    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    float4 x = ok ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+    const float mu = s * (1.0f / (4 * GROUP));
+    const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, GROUP);
+    const float rstd = rsqrtf(q * (1.0f / (4 * GROUP)) + 1e-5f);
+    if (!ok) return;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + 4 * c4);
+    float4 y;
+    y.x = dx * rstd * ga.x + be.x;
+    y.y = dy * rstd * ga.y + be.y;
+    y.z = dz * rstd * ga.z + be.z;
+    y.w = dw * rstd * ga.w + be.w;
+    *reinterpret_cast<float4*>(out + r * ld + 4 * c4) = y;
+  }
+};
+
+// LSTM pre-activations straight from the accumulators into the fragment layout (common.h)
+struct EpiLstmPre {
+  static constexpr bool DIRECT = true;
+  float* pre;
+  const float* b_ih[2];
+  const float* b_hh[2];
+  SeqGeom g;
+  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
+    const int st = tile / g.len, t = tile - st * g.len;
+    const int j = cb * 32 + c;
+    const float bias = b_ih[d][j] + b_hh[d][j];
+    float* base = pre + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)cb * 1024 + hh * 128 + c * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v;
+      v.x = acc[4 * q + 0] + bias;
+      v.y = acc[4 * q + 1] + bias;
+      v.z = acc[4 * q + 2] + bias;
+      v.w = acc[4 * q + 3] + bias;
+      *reinterpret_cast<float4*>(base + q * 256) = v;
+    }
+  }
+};

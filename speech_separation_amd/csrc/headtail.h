@@ -1,0 +1,177 @@
+// headtail.h -- bandwidth-bound ends of the path (encoder + video gate + chunking; overlap-add +
+// post-processing + skip + transposed-conv decoder).  fp32, coalesced 16-byte accesses, LayerNorm
+// statistics by sub-wave shuffles.
+#pragma once
+#include "common.h"
+#include "gemm_ws.h"
+
+// ------------------------------------------------------------------------------------------------
+// video branch, step 1: Linear(Cv -> HV/2) for both speakers (shared weights), concatenated
+//   reference: dptn_wav.py:173-179.   e* (B,Cv,Tv) -> vid (B,Tv,HV)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void video_linear_kernel(const float* __restrict__ e1,
+                                                            const float* __restrict__ e2,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ vid, int Cv, int Tv, int half) {
+  const int b = blockIdx.x, spk = blockIdx.y;
+  const float* e = (spk ? e2 : e1) + (int64_t)b * Cv * Tv;
+  for (int idx = threadIdx.x; idx < half * Tv; idx += blockDim.x) {
+    const int o = idx / Tv, t = idx - o * Tv;
+    const float* w = W + (int64_t)o * Cv;
+    float acc = 0.f;
+    for (int cc = 0; cc < Cv; ++cc) acc = fmaf(w[cc], e[(int64_t)cc * Tv + t], acc);
+    vid[((int64_t)b * Tv + t) * (2 * half) + spk * half + o] = acc + bias[o];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: encoder Conv1d(1->N,k,stride) + [linear interpolation Tv->L of vid, LayerNorm(N), * tanh(gate)]
+//       + write the frame-major latent E[b][l][n] and the chunked tokens X[b][s][k][n]
+//   reference: dptn_wav.py:180-184, dprnn.py:122-136.   GROUP = N/4 lanes per frame.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restrict__ mix,
+                                                            const float* __restrict__ wenc,  // (N,1,k)
+                                                            const float* __restrict__ vid,   // (B,Tv,N) or null
+                                                            const float* __restrict__ gate,
+                                                            const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b,
+                                                            float* __restrict__ E, float* __restrict__ X,
+                                                            int64_t T, int L, int kenc, int stride, int Tv, int S,
+                                                            int K, int P) {
+  constexpr int GROUP = N / 4;
+  constexpr int FPB = 256 / GROUP;  // frames per block
+  const int b = blockIdx.y;
+  const int l = blockIdx.x * FPB + threadIdx.x / GROUP;
+  const int c4 = threadIdx.x % GROUP;
+  const bool ok = l < L;
+  const int lc = ok ? l : L - 1;
+
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* m = mix + (int64_t)b * T + (int64_t)stride * lc;
+  for (int j = 0; j < kenc; ++j) {
+    const float x = m[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaf(wenc[(4 * c4 + i) * kenc + j], x, v[i]);
+  }
+  if (vid != nullptr) {
+    // F.interpolate(mode="linear", align_corners=False)
+    const float scale = (float)Tv / (float)L;
+    float src = ((float)lc + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const int i0 = (int)floorf(src);
+    const int i1 = i0 + 1 < Tv ? i0 + 1 : Tv - 1;
+    const float lam = src - (float)i0;
+    const float4 a = *reinterpret_cast<const float4*>(vid + ((int64_t)b * Tv + i0) * N + 4 * c4);
+    const float4 bb = *reinterpret_cast<const float4*>(vid + ((int64_t)b * Tv + i1) * N + 4 * c4);
+    float u[4] = {a.x * (1.f - lam) + bb.x * lam, a.y * (1.f - lam) + bb.y * lam, a.z * (1.f - lam) + bb.z * lam,
+                  a.w * (1.f - lam) + bb.w * lam};
+    float s = (u[0] + u[1]) + (u[2] + u[3]);
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+    const float mu = s * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[i] -= mu;
+      q += u[i] * u[i];
+    }
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, GROUP);
+    const float rstd = rsqrtf(q * (1.0f / N) + 1e-5f);
+    const float tg = tanhf(*gate);
+    const float4 ga = *reinterpret_cast<const float4*>(ln_w + 4 * c4);
+    const float4 be = *reinterpret_cast<const float4*>(ln_b + 4 * c4);
+    v[0] += tg * (u[0] * rstd * ga.x + be.x);
+    v[1] += tg * (u[1] * rstd * ga.y + be.y);
+    v[2] += tg * (u[2] * rstd * ga.z + be.z);
+    v[3] += tg * (u[3] * rstd * ga.w + be.w);
+  }
+  if (!ok) return;
+  const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(E + ((int64_t)b * L + l) * N + 4 * c4) = o4;
+  // chunks s with P*s <= l < P*s + K   (F.unfold semantics: trailing frames belong to no chunk)
+  int s_hi = l / P;
+  if (s_hi > S - 1) s_hi = S - 1;
+  for (int s = s_hi; s >= 0 && l - P * s < K; --s)
+    *reinterpret_cast<float4*>(X + (((int64_t)b * S + s) * K + (l - P * s)) * N + 4 * c4) = o4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail stage 2 (GEMM-engine hooks): rows are (spk, b, frame t).  A row = overlap-add of the separated
+// tokens shifted by `left` frames (dptn_wav.py:49-57, dprnn.py:145-163); the GEMM is the shared
+// post-processing 1x1 conv (dptn_wav.py:31-33,59); the epilogue adds bias + fused latent E (skip,
+// dptn_wav.py:188) and projects on the k decoder taps (ConvTranspose1d weights, dptn_wav.py:167-169).
+// ------------------------------------------------------------------------------------------------
+struct ALoadOla {
+  const float* Z;  // (M, 2N) separated tokens
+  int N, B, L, S, K, P, left, ola, bm;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= (int64_t)2 * B * L) return acc;
+    const int spk = (int)(r / ((int64_t)B * L));
+    const int64_t rem = r - (int64_t)spk * B * L;
+    const int b = (int)(rem / L);
+    const int t = (int)(rem - (int64_t)b * L) - left;
+    if (t < 0 || t >= ola) return acc;
+    int s_hi = t / P;
+    if (s_hi > S - 1) s_hi = S - 1;
+    for (int s = s_hi; s >= 0 && t - P * s < K; --s) {
+      const float4 z = *reinterpret_cast<const float4*>(Z + (((int64_t)b * S + s) * K + (t - P * s)) * (2 * N) +
+                                                        spk * N + 4 * k4);
+      acc.x += z.x; acc.y += z.y; acc.z += z.z; acc.w += z.w;
+    }
+    return acc;
+  }
+};
+
+template <int GROUP>
+struct EpiSkipDecoderTaps {
+  static constexpr bool DIRECT = false;
+  float* D;            // (2*B*L, 8) decoder tap products
+  const float* bias;   // postprocessing bias
+  const float* E;      // (B*L, N)
+  const float* wdec;   // (N,1,k)
+  int64_t BL;          // B*L
+  int kenc, bm;
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    const bool ok = r < 2 * BL;
+    const int64_t e = ok ? (r % BL) : 0;
+    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    const float4 x = *reinterpret_cast<const float4*>(E + e * (4 * GROUP) + 4 * c4);
+    v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+    float mine = 0.f;
+    for (int j = 0; j < kenc; ++j) {
+      float s = v.x * wdec[(4 * c4 + 0) * kenc + j] + v.y * wdec[(4 * c4 + 1) * kenc + j] +
+                v.z * wdec[(4 * c4 + 2) * kenc + j] + v.w * wdec[(4 * c4 + 3) * kenc + j];
+#pragma unroll
+      for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+      if (c4 == j) mine = s;
+    }
+    if (ok && c4 < 8) D[r * 8 + c4] = c4 < kenc ? mine : 0.f;
+  }
+};
+
+// tail stage 3: y[n] = sum over taps j == n (mod stride) of D[(n-j)/stride][j]; zero pad to T
+//   (ConvTranspose1d scatter turned into a gather; dptn_wav.py:188-192)
+__global__ __launch_bounds__(256) void decoder_gather_kernel(const float* __restrict__ D, float* __restrict__ s1,
+                                                              float* __restrict__ s2, int B, int64_t T, int L,
+                                                              int kenc, int stride, int pad_left) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, spk = blockIdx.z;
+  if (n >= T) return;
+  const int64_t m = n - pad_left;
+  const int64_t ndec = (int64_t)(L - 1) * stride + kenc;
+  float acc = 0.f;
+  if (m >= 0 && m < ndec) {
+    const float* Db = D + ((int64_t)spk * B + b) * L * 8;
+    for (int j = (int)(m % stride); j < kenc; j += stride) {
+      const int64_t i = (m - j) / stride;
+      if (i >= 0 && i < L) acc += Db[i * 8 + j];
+    }
+  }
+  (spk ? s2 : s1)[(int64_t)b * T + n] = acc;
+}

@@ -1,0 +1,118 @@
+// lstm.h -- persistent bidirectional LSTM recurrence for gfx950 (H = 128).
+//
+// Reference semantics: nn.LSTM(N, 128, bidirectional, batch_first) inside TransformerDPRNN
+// (src/model/dptn.py:23-29,49): gates i|f|g|o, zero initial state, reverse direction runs t = T-1..0.
+// The input projection x W_ih^T + b_ih + b_hh was produced by the GEMM engine (EpiLstmPre); this
+// kernel only carries the serial part  gates_t = PRE_t + h_{t-1} W_hh^T.
+//
+// Mapping: one workgroup (4 waves, one per SIMD) = one direction x one tile of 32 sequences, for ALL
+// time steps.  W_hh (512x128 fp32 = 256 KiB) does not fit the 160 KiB LDS, but it fits the register
+// file: wave w keeps the rows of W_hh belonging to hidden units [32w, 32w+32) for all four gates as
+// 4 x 64 ready-made MFMA B-fragments (256 VGPR/AGPR per lane).  Per step:
+//     acc[g] <- PRE tile (one 16-byte load per 4 accumulator registers, fragment layout)
+//     acc[g] += h_{t-1}[32 x 128] * W_hh[g-slice]^T      256 x v_mfma_f32_32x32x2_f32 per wave
+//     i,f,g,o are the SAME accumulator slot in the four tiles -> the cell update is lane-local
+//     h_t -> LDS (double buffered, one barrier per step) and -> HBM as ReLU(h_t) (the only consumer is
+//     ffn = ReLU -> Linear, dptn.py:30-33,50)
+#pragma once
+#include "common.h"
+
+constexpr int LSTM_H = 128;
+constexpr int LSTM_LDH = LSTM_H + 4;
+constexpr size_t LSTM_LDS_BYTES = sizeof(float) * 2 * 32 * LSTM_LDH;
+
+__global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __restrict__ pre,
+                                                               const float* __restrict__ whh_f,
+                                                               const float* __restrict__ whh_b,
+                                                               float* __restrict__ hc, int ldh, SeqGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;  // [2][32][LSTM_LDH]
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int st = blockIdx.x, d = blockIdx.y;
+  const float* whh = d ? whh_b : whh_f;
+
+  // ---- W_hh slice -> registers (B fragments) ---------------------------------------------------
+  float wf[4][64];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const float* wrow = whh + (int64_t)(gi * LSTM_H + 32 * w + c) * LSTM_H + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * m);
+      wf[gi][4 * m + 0] = v.x;
+      wf[gi][4 * m + 1] = v.y;
+      wf[gi][4 * m + 2] = v.z;
+      wf[gi][4 * m + 3] = v.w;
+    }
+  }
+
+  // ---- per-lane output rows: token offset of (sequence rho, t=0) or -1 -----------------------
+  int tokbase[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = st * 32 + ROW32(r, hh);
+    tokbase[r] = q < g.nseq ? (int)seq_token_base(g, q) : -1;
+  }
+  const int tstride = seq_token_stride(g);
+
+  for (int i = tid; i < 32 * LSTM_LDH; i += 256) Hs[i] = 0.f;  // h_{-1} = 0 (buffer 0)
+  f32x16 cst = zero16();
+  __syncthreads();
+
+  const float* pre_tile0 = pre + pre_tile_offset(d, st, 0, g.nst, g.len) + hh * 128 + c * 4;
+  const int outcol = d * LSTM_H + 32 * w + c;
+
+  for (int step = 0; step < g.len; ++step) {
+    const int t = d ? g.len - 1 - step : step;
+    const float* hcur = Hs + (step & 1) * 32 * LSTM_LDH;
+    float* hnext = Hs + ((step + 1) & 1) * 32 * LSTM_LDH;
+
+    // accumulators start from the pre-activations
+    f32x16 acc[4];
+    {
+      const float* p = pre_tile0 + (int64_t)t * (512 * 32);
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(p + (gi * 4 + w) * 1024 + q * 256);
+          acc[gi][4 * q + 0] = v.x;
+          acc[gi][4 * q + 1] = v.y;
+          acc[gi][4 * q + 2] = v.z;
+          acc[gi][4 * q + 3] = v.w;
+        }
+      }
+    }
+    // h_{t-1} W_hh^T
+    {
+      const float* arow = hcur + c * LSTM_LDH + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          acc[gi] = mfma32(a.x, wf[gi][4 * m + 0], acc[gi]);
+          acc[gi] = mfma32(a.y, wf[gi][4 * m + 1], acc[gi]);
+          acc[gi] = mfma32(a.z, wf[gi][4 * m + 2], acc[gi]);
+          acc[gi] = mfma32(a.w, wf[gi][4 * m + 3], acc[gi]);
+        }
+      }
+    }
+    // cell update (lane-local) + publish h_t
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float ig = fast_sigmoid(acc[0][r]);
+      const float fg = fast_sigmoid(acc[1][r]);
+      const float gg = fast_tanh(acc[2][r]);
+      const float og = fast_sigmoid(acc[3][r]);
+      const float cn = fg * cst[r] + ig * gg;
+      cst[r] = cn;
+      const float hn = og * fast_tanh(cn);
+      hnext[ROW32(r, hh) * LSTM_LDH + 32 * w + c] = hn;
+      if (tokbase[r] >= 0) hc[(int64_t)(tokbase[r] + t * tstride) * ldh + outcol] = fmaxf(hn, 0.f);
+    }
+    __syncthreads();
+  }
+}

@@ -1,0 +1,215 @@
+"""Host-side driver of libdptnav: owns the handle and the workspace tensor, hands raw device
+pointers of torch tensors to the C ABI.  torch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .spec import DPTNConfig, state_dict_spec
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check(t: torch.Tensor, name: str, shape: Tuple[int, ...], device: torch.device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.device != device:
+        raise ValueError(f"{name}: lives on {t.device}, engine is on {device}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+class DptnEngine:
+    """One handle <-> one device <-> the caller's current stream (include/dptnav.h threading contract)."""
+
+    def __init__(self, cfg: DPTNConfig, device: torch.device | str = "cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DptnEngine needs a GPU device (PyTorch-ROCm 'cuda:N'); there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = _lib.load()
+        c = _lib.DptnavConfig(cfg.num_features, cfg.video_emb_size, cfg.hidden_video, cfg.kernel_size_enc,
+                              cfg.hidden_dim, cfg.num_blocks, cfg.chunk_size, cfg.step_size, cfg.num_heads,
+                              int(cfg.bidir), int(cfg.audio_only))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.dptnav_create(C.byref(c), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"dptnav_create failed ({rc}): {self.lib.dptnav_last_error(None).decode()}")
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+        self._bound: Optional[list] = None  # keeps the tensors alive
+        # the library's slot table must equal the Python spec (both restate the reference's state_dict)
+        spec = state_dict_spec(cfg)
+        n = self.lib.dptnav_num_weights(h)
+        names = [self.lib.dptnav_weight_name(h, i).decode() for i in range(n)]
+        if names != [k for k, _ in spec]:
+            raise RuntimeError("libdptnav weight table disagrees with speech_separation_amd.spec")
+        self.slots = spec
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.dptnav_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, rc: int, what: str):
+        raise RuntimeError(f"{what} failed ({rc}): {self.lib.dptnav_last_error(self._h).decode()}")
+
+    # ------------------------------------------------------------------ weights
+    def bind(self, params: Mapping[str, torch.Tensor]):
+        """Borrow the parameter storages (no copies): call again if they are re-allocated."""
+        keep, ptrs = [], (C.c_void_p * len(self.slots))()
+        for i, (key, shape) in enumerate(self.slots):
+            if key not in params:
+                raise KeyError(f"missing parameter {key}")
+            t = params[key].detach()
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{key}: expected {tuple(shape)}, got {tuple(t.shape)}")
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError(f"{key}: must be contiguous float32 on {self.device}")
+            keep.append(t)
+            ptrs[i] = t.data_ptr()
+        rc = self.lib.dptnav_bind_weights(self._h, ptrs, len(self.slots))
+        if rc:
+            self._raise(rc, "dptnav_bind_weights")
+        self._bound = keep
+        self._bound_ptrs = tuple(t.data_ptr() for t in keep)
+
+    def bound_to(self, params: Mapping[str, torch.Tensor]) -> bool:
+        if self._bound is None:
+            return False
+        return self._bound_ptrs == tuple(params[k].data_ptr() for k, _ in self.slots)
+
+    # ------------------------------------------------------------------ sizes / workspace
+    def frames(self, T: int) -> int:
+        return int(self.lib.dptnav_frames(self._h, T))
+
+    def chunks(self, T: int) -> int:
+        return int(self.lib.dptnav_chunks(self._h, T))
+
+    def workspace_bytes(self, B: int, T: int, Tv: int) -> int:
+        n = int(self.lib.dptnav_workspace_bytes(self._h, B, T, Tv))
+        if n == 0:
+            raise RuntimeError(f"unsupported shape: {self.lib.dptnav_last_error(self._h).decode()}")
+        return n
+
+    def _workspace(self, B: int, T: int, Tv: int) -> torch.Tensor:
+        need = self.workspace_bytes(B, T, Tv)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        assert self._ws.data_ptr() % 256 == 0
+        return self._ws
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def flops_per_mixture(self, T: int) -> float:
+        return float(self.lib.dptnav_flops_per_mixture(self._h, T))
+
+    def min_bytes_per_mixture(self, T: int) -> float:
+        return float(self.lib.dptnav_min_bytes_per_mixture(self._h, T))
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, mix: torch.Tensor, e1: Optional[torch.Tensor] = None, e2: Optional[torch.Tensor] = None,
+                out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        cfg = self.cfg
+        if mix.dim() != 2:
+            raise ValueError(f"mix: expected (B,T), got {tuple(mix.shape)}")
+        B, T = mix.shape
+        mix = _check(mix, "mix", (B, T), self.device)
+        Tv = 1
+        if not cfg.audio_only:
+            if e1 is None or e2 is None:
+                raise ValueError("s1_embedding and s2_embedding are required for the audio-visual model")
+            Tv = e1.shape[-1]
+            e1 = _check(e1, "s1_embedding", (B, cfg.video_emb_size, Tv), self.device)
+            e2 = _check(e2, "s2_embedding", (B, cfg.video_emb_size, Tv), self.device)
+        else:
+            e1 = e2 = None
+        ws = self._workspace(B, T, Tv)
+        s1, s2 = out if out is not None else (torch.empty_like(mix), torch.empty_like(mix))
+        rc = self.lib.dptnav_forward(self._h, mix.data_ptr(), _ptr(e1), _ptr(e2), B, T, Tv, s1.data_ptr(),
+                                     s2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_forward")
+        return s1, s2
+
+    # ------------------------------------------------------------------ stages (parity tests / profiling)
+    def stage_head(self, mix, e1=None, e2=None):
+        cfg = self.cfg
+        B, T = mix.shape
+        Tv = 1 if cfg.audio_only else e1.shape[-1]
+        L, S = self.frames(T), self.chunks(T)
+        ws = self._workspace(B, T, Tv)
+        enc = torch.empty(B, L, cfg.num_features, device=self.device)
+        chk = torch.empty(B, S, cfg.chunk_size, cfg.num_features, device=self.device)
+        rc = self.lib.dptnav_stage_head(self._h, mix.contiguous().data_ptr(),
+                                        _ptr(None if e1 is None else e1.contiguous()),
+                                        _ptr(None if e2 is None else e2.contiguous()), B, T, Tv, enc.data_ptr(),
+                                        chk.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_stage_head")
+        return enc, chk
+
+    def _path_T(self, S: int) -> int:
+        L = (S - 1) * self.cfg.step_size + self.cfg.chunk_size
+        return (L - 1) * self.cfg.stride_enc + self.cfg.kernel_size_enc
+
+    def stage_path(self, block: int, path: int, x: torch.Tensor) -> torch.Tensor:
+        B, S, K, N = x.shape
+        x = _check(x, "x", (B, S, self.cfg.chunk_size, self.cfg.num_features), self.device)
+        ws = self._workspace(B, self._path_T(S), 1)
+        y = torch.empty_like(x)
+        rc = self.lib.dptnav_stage_path(self._h, block, path, x.data_ptr(), y.data_ptr(), B, S, ws.data_ptr(),
+                                        ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_stage_path")
+        return y
+
+    def stage_tail(self, x: torch.Tensor, encoded: torch.Tensor, T: int):
+        B = x.shape[0]
+        ws = self._workspace(B, T, 1)
+        s1 = torch.empty(B, T, device=self.device)
+        s2 = torch.empty(B, T, device=self.device)
+        rc = self.lib.dptnav_stage_tail(self._h, x.contiguous().data_ptr(), encoded.contiguous().data_ptr(), B, T,
+                                        s1.data_ptr(), s2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_stage_tail")
+        return s1, s2
+
+    def tap(self, name: str, B: int, T: int, Tv: int = 1) -> torch.Tensor:
+        """View of an intermediate left in the workspace by the last stage_path/forward call."""
+        off, n = C.c_size_t(), C.c_size_t()
+        rc = self.lib.dptnav_workspace_tap(self._h, B, T, Tv, name.encode(), C.byref(off), C.byref(n))
+        if rc:
+            self._raise(rc, "dptnav_workspace_tap")
+        ws = self._workspace(B, T, Tv)
+        return ws[off.value:off.value + 4 * n.value].view(torch.float32)
+
+
+def params_to_device(sd: Mapping[str, "object"], device) -> Dict[str, torch.Tensor]:
+    """numpy / torch state_dict -> contiguous float32 device tensors."""
+    out = {}
+    for k, v in sd.items():
+        t = v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+        out[k] = t.to(device=device, dtype=torch.float32).contiguous()
+    return out

@@ -1,0 +1,148 @@
+"""Drop-in ``nn.Module``s for the reference's DPTN raw-waveform separators, backed by libdptnav.
+
+Mirrors (does not import) the reference interface for this path:
+  * ``DPTNAVWavEncDec(num_features, video_emb_size, hidden_video, kernel_size_enc, hidden_dim, num_blocks,
+    chunk_size, step_size, num_heads, dropout, bidir)``            src/model/dptn_wav.py:137-150
+  * ``DPTNWavEncDec(num_features, kernel_size_enc, ...)``           src/model/dptn_wav.py:72-83
+  * ``forward(mix, s1_embedding, s2_embedding, **batch) -> {"s1_pred","s2_pred"}``  dptn_wav.py:171,194
+    -- called as ``self.model(**batch)`` by src/trainer/trainer.py:40 and inferencer.py:117, so unknown
+    batch keys (mix_spectrogram, s1, s2, paths, ...) must be accepted and ignored.
+  * ``state_dict()`` keys/shapes == the reference's, so ``model_best.pth`` loads
+    through base_trainer.py:539-560 unchanged.
+  * ``str(model)`` ends with the two parameter-count lines of dptn_wav.py:196-207.
+
+Select it from the reference's Hydra CLI with ``model._target_=speech_separation_amd.DPTNAVWavEncDec``
+(INTEGRATION.md).  The forward runs ONLY on the HIP library: no PyTorch operators are used for compute
+and there is no CPU fallback -- a missing extension or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .engine import DptnEngine
+from .spec import DPTNConfig, state_dict_spec
+
+
+class _Node(nn.Module):
+    """Pure parameter container (never called): gives nested state_dict keys such as
+    ``dprnn.model.0.intra_chunk_block.mha.out_proj.weight``."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: compute happens in libdptnav, not in torch")
+
+
+def _init_like_torch(key: str, p: torch.Tensor, cfg: DPTNConfig) -> None:
+    """Default initialisers of the stock modules the reference instantiates (so a from-scratch run
+    starts from the same distributions): nn.LSTM U(+-1/sqrt(H)); nn.Linear/Conv kaiming_uniform(a=sqrt 5)
+    == U(+-1/sqrt(fan_in)) with the matching bias bound; nn.MultiheadAttention xavier_uniform in_proj,
+    zero biases; LayerNorm 1/0; PReLU 0.25; gate ~ N(0,1) (dptn_wav.py:155)."""
+    leaf2 = ".".join(key.split(".")[-2:])
+    with torch.no_grad():
+        if key == "gate":
+            p.normal_()
+        elif key.endswith("speakers_separation.0.weight"):
+            p.fill_(0.25)
+        elif ".rnn." in key:
+            b = 1.0 / math.sqrt(cfg.hidden_dim)
+            p.uniform_(-b, b)
+        elif leaf2 in ("ln1.weight", "ln2.weight", "video_ln.weight"):
+            p.fill_(1.0)
+        elif leaf2 in ("ln1.bias", "ln2.bias", "video_ln.bias", "mha.in_proj_bias", "out_proj.bias"):
+            p.zero_()
+        elif leaf2 == "mha.in_proj_weight":
+            nn.init.xavier_uniform_(p)
+        elif key.endswith("weight"):
+            fan_in = p[0].numel()
+            b = 1.0 / math.sqrt(fan_in)
+            p.uniform_(-b, b)
+        else:  # biases of Linear / Conv: U(+-1/sqrt(fan_in of the matching weight))
+            fan_in = {"visual_compression.bias": cfg.video_emb_size, "ffn.1.bias": None}.get(leaf2, cfg.num_features)
+            if fan_in is None:
+                fan_in = cfg.hidden_dim * (2 if (cfg.bidir or "intra_chunk_block" in key) else 1)
+            b = 1.0 / math.sqrt(fan_in)
+            p.uniform_(-b, b)
+
+
+class _DPTNBase(nn.Module):
+    def __init__(self, cfg: DPTNConfig):
+        super().__init__()
+        self.cfg = cfg
+        for key, shape in state_dict_spec(cfg):
+            parts = key.split(".")
+            node: nn.Module = self
+            for name in parts[:-1]:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            p = nn.Parameter(torch.empty(*shape))
+            node.register_parameter(parts[-1], p)
+            _init_like_torch(key, p, cfg)
+        self._engine: Optional[DptnEngine] = None
+
+    # -- engine management -------------------------------------------------------------------
+    def _params(self) -> Dict[str, torch.Tensor]:
+        return dict(self.named_parameters())
+
+    def _get_engine(self, device: torch.device) -> DptnEngine:
+        if device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__} computes only on an AMD GPU through libdptnav "
+                               f"(got a {device} tensor); there is no CPU/PyTorch fallback")
+        eng = self._engine
+        if eng is None or eng.device != device:
+            eng = DptnEngine(self.cfg, device)
+            self._engine = eng
+        params = self._params()
+        for k, p in params.items():
+            if p.device != device:
+                raise RuntimeError(f"parameter {k} is on {p.device} but the input is on {device}: call model.to(device)")
+        if not eng.bound_to(params):
+            eng.bind(params)  # borrows the nn.Parameter storages (optimizer / load_state_dict stay in charge)
+        return eng
+
+    def _run(self, mix, e1, e2):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "libdptnav implements the forward (inference) path; the backward kernels for the training step "
+                "(BASELINE config 4, SURVEY.md 8f N1) are not built yet -- call under torch.no_grad()")
+        eng = self._get_engine(mix.device)
+        s1, s2 = eng.forward(mix, e1, e2)
+        return {"s1_pred": s1, "s2_pred": s2}
+
+    def __str__(self):
+        all_parameters = sum(p.numel() for p in self.parameters())
+        trainable_parameters = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return (super().__str__() + f"\nAll parameters: {all_parameters}"
+                + f"\nTrainable parameters: {trainable_parameters}")
+
+
+class DPTNAVWavEncDec(_DPTNBase):
+    """Audio-visual DPTN (BASELINE configs 3/4) -- same constructor as the reference class of that name."""
+
+    def __init__(self, num_features=64, video_emb_size=1024, hidden_video=128, kernel_size_enc=2, hidden_dim=32,
+                 num_blocks=6, chunk_size=10, step_size=5, num_heads=4, dropout=0.1, bidir=True):
+        super().__init__(DPTNConfig(num_features=num_features, video_emb_size=video_emb_size,
+                                    hidden_video=hidden_video, kernel_size_enc=kernel_size_enc,
+                                    hidden_dim=hidden_dim, num_blocks=num_blocks, chunk_size=chunk_size,
+                                    step_size=step_size, num_heads=num_heads, dropout=dropout, bidir=bool(bidir),
+                                    audio_only=False))
+
+    def forward(self, mix, s1_embedding, s2_embedding, **batch):
+        return self._run(mix, s1_embedding, s2_embedding)
+
+
+class DPTNWavEncDec(_DPTNBase):
+    """Audio-only DPTN (BASELINE config 2) -- same constructor as the reference class of that name."""
+
+    def __init__(self, num_features=64, kernel_size_enc=2, hidden_dim=32, num_blocks=6, chunk_size=10, step_size=5,
+                 num_heads=4, dropout=0.1, bidir=True):
+        super().__init__(DPTNConfig(num_features=num_features, kernel_size_enc=kernel_size_enc,
+                                    hidden_dim=hidden_dim, num_blocks=num_blocks, chunk_size=chunk_size,
+                                    step_size=step_size, num_heads=num_heads, dropout=dropout, bidir=bool(bidir),
+                                    audio_only=True))
+
+    def forward(self, mix, **batch):
+        return self._run(mix, None, None)
