@@ -122,6 +122,19 @@ int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int
  * [ReLU(h_fwd|h_bwd)].  Returns non-zero for an unknown name. */
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* offset_bytes,
                          size_t* numel);
+/* Opt-in per-kernel timing: while enabled every launch is bracketed by two hipEvents recorded on the
+ * launch stream (so the figures are device time of that kernel, not host time).  collect() waits for
+ * the recorded events and accumulates them per kernel class; ms()/count() read the accumulators.
+ * Kernel classes: video_linear, encoder_fuse, qkv_gemm, attention, outproj_ln_gemm, lstm_pre_gemm,
+ * lstm_recurrence, ffn_ln_gemm, sep_gemm, postproc_gemm, decoder_gather.  Not graph-capturable. */
+int dptnav_profile_enable(dptnav_handle h, int on);
+int dptnav_profile_collect(dptnav_handle h);
+int dptnav_profile_reset(dptnav_handle h);
+int dptnav_profile_num(void);
+const char* dptnav_profile_name(int cls);
+double dptnav_profile_ms(dptnav_handle h, int cls);
+int64_t dptnav_profile_count(dptnav_handle h, int cls);
+
 /* Algorithmic cost model used for roofline reporting. */
 double dptnav_flops_per_mixture(dptnav_handle h, int64_t T);
 double dptnav_min_bytes_per_mixture(dptnav_handle h, int64_t T);

@@ -35,8 +35,34 @@ struct Plan {  // workspace offsets in floats
 
 }  // namespace
 
+enum ProfCat { CAT_VIDEO = 0, CAT_ENCODER, CAT_QKV, CAT_ATTN, CAT_OUTPROJ, CAT_LSTM_PRE, CAT_LSTM, CAT_FFN,
+               CAT_SEP, CAT_POST, CAT_DECODER, CAT_COUNT };
+static const char* const kProfNames[CAT_COUNT] = {
+    "video_linear", "encoder_fuse", "qkv_gemm", "attention", "outproj_ln_gemm", "lstm_pre_gemm",
+    "lstm_recurrence", "ffn_ln_gemm", "sep_gemm", "postproc_gemm", "decoder_gather"};
+
+struct ProfRec {
+  int cat;
+  hipEvent_t a, b;
+};
+
 struct dptnav_ctx {
   dptnav_config cfg;
+  bool prof_on = false;
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[CAT_COUNT] = {0};
+  int64_t prof_n[CAT_COUNT] = {0};
+  hipEvent_t prof_event() {
+    if (!prof_pool.empty()) {
+      hipEvent_t e = prof_pool.back();
+      prof_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
   std::vector<std::string> names;
   std::vector<int64_t> numel;
   std::vector<const float*> ptr;
@@ -65,6 +91,25 @@ struct dptnav_ctx {
 namespace {
 
 inline size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
+
+// Opt-in per-kernel timing: HIP events recorded on the launch stream around one launch.
+struct ProfScope {
+  dptnav_ctx* c;
+  hipStream_t st;
+  ProfRec rec;
+  ProfScope(dptnav_ctx* c_, int cat, hipStream_t st_) : c(c_), st(st_) {
+    if (!c->prof_on) return;
+    rec.cat = cat;
+    rec.a = c->prof_event();
+    rec.b = c->prof_event();
+    hipEventRecord(rec.a, st);
+  }
+  ~ProfScope() {
+    if (!c->prof_on) return;
+    hipEventRecord(rec.b, st);
+    c->prof_pending.push_back(rec);
+  }
+};
 
 void build_names(dptnav_ctx* c) {
   const dptnav_config& g = c->cfg;
@@ -215,6 +260,7 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
   if (int rc = set_lds(c, kern, lds, "attention")) return rc;
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
+  ProfScope ps(c, CAT_ATTN, st);
   hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale);
   LAUNCH_CHECK(c, "attention");
   return DPTNAV_OK;
@@ -236,11 +282,12 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
 template <int KIN, int NT, int WR, int WC, class AL, class EP>
-int launch_gemm(dptnav_ctx* c, const char* what, const float* W, int64_t ntiles, int colgroups, int cap,
+int launch_gemm(dptnav_ctx* c, int cat, const char* what, const float* W, int64_t ntiles, int colgroups, int cap,
                 const AL& al, const EP& ep, hipStream_t st, const float* Walt = nullptr) {
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
   if (int rc = set_lds(c, kern, lds, what)) return rc;
+  ProfScope ps(c, cat, st);
   hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, cap), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
                      al, ep);
   LAUNCH_CHECK(c, what);
@@ -265,7 +312,7 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
   {
     ALoadDense al{x_in, M, N, BM};
     EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
-    if (int rc = launch_gemm<N, 3, WR, WC>(c, "qkv gemm", w.in_w, ntiles, 1, 512, al, ep, st)) return rc;
+    if (int rc = launch_gemm<N, 3, WR, WC>(c, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, 512, al, ep, st)) return rc;
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
@@ -273,19 +320,20 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
   {
     ALoadDense al{att, M, N, BM};
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
-    if (int rc = launch_gemm<N, 1, WR, WC>(c, "out-proj gemm", w.out_w, ntiles, 1, 1024, al, ep, st)) return rc;
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, 1024, al, ep, st)) return rc;
   }
   // K4: LSTM pre-activations for every (direction, sequence tile, position)
   {
     ALoadSeqTile al{y1, N, geom};
     EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
-    if (int rc = launch_gemm<N, 4, 1, 4>(c, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, 512, al, ep, st, w.w_ih[1]))
+    if (int rc = launch_gemm<N, 4, 1, 4>(c, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, 512, al, ep, st, w.w_ih[1]))
       return rc;
   }
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
   {
     if (int rc = set_lds(c, lstm_recurrence_kernel, LSTM_LDS_BYTES, "lstm")) return rc;
+    ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(lstm_recurrence_kernel, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0],
                        w.w_hh[1], hc, w.ndir * LSTM_H, geom);
     LAUNCH_CHECK(c, "lstm");
@@ -295,10 +343,10 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
     if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
-      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
     } else {
       ALoadDense al{hc, M, LSTM_H, BM};
-      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
     }
   }
   return DPTNAV_OK;
@@ -311,12 +359,14 @@ int run_head(dptnav_ctx* c, const float* mix, const float* e1, const float* e2, 
   const float* vid = nullptr;
   if (!g.audio_only) {
     float* v = ws + pl.vid;
+    ProfScope ps(c, CAT_VIDEO, st);
     hipLaunchKernelGGL(video_linear_kernel, dim3(B, 2), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
                        c->w("visual_compression.bias"), v, g.video_emb_size, Tv, g.hidden_video / 2);
     LAUNCH_CHECK(c, "video linear");
     vid = v;
   }
   constexpr int FPB = 256 / (N / 4);
+  ProfScope ps(c, CAT_ENCODER, st);
   hipLaunchKernelGGL(encoder_fuse_kernel<N>, dim3((unsigned)((pl.L + FPB - 1) / FPB), B), dim3(256), 0, st, mix,
                      c->w("encoder.weight"), vid, g.audio_only ? nullptr : c->w("gate"),
                      g.audio_only ? nullptr : c->w("video_ln.weight"), g.audio_only ? nullptr : c->w("video_ln.bias"),
@@ -337,7 +387,7 @@ int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, fl
   {
     ALoadDensePReLU al{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
     EpiBiasStore ep{Z, c->w("dprnn.speakers_separation.1.bias"), M, 2 * N, 32, 2 * N};
-    if (int rc = launch_gemm<N, N / 64, 1, 4>(c, "separation gemm", c->w("dprnn.speakers_separation.1.weight"),
+    if (int rc = launch_gemm<N, N / 64, 1, 4>(c, CAT_SEP, "separation gemm", c->w("dprnn.speakers_separation.1.weight"),
                                               (M + 31) / 32, 1, 1024, al, ep, st))
       return rc;
   }
@@ -349,7 +399,7 @@ int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, fl
     ALoadOla al{Z, N, B, (int)pl.L, (int)pl.S, g.chunk_size, g.step_size, left, ola, BM};
     EpiSkipDecoderTaps<GROUP> ep{D, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"),
                                  (int64_t)B * pl.L, g.kernel_size_enc, BM};
-    if (int rc = launch_gemm<N, 1, WR, WC>(c, "postproc gemm", c->w("dprnn.postprocessing.0.weight"),
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, CAT_POST, "postproc gemm", c->w("dprnn.postprocessing.0.weight"),
                                            (rows + BM - 1) / BM, 1, 1024, al, ep, st))
       return rc;
   }
@@ -357,6 +407,7 @@ int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, fl
   {
     const int64_t ndec = (pl.L - 1) * c->stride + g.kernel_size_enc;
     const int pad_left = (int)((T - ndec) / 2);
+    ProfScope ps(c, CAT_DECODER, st);
     hipLaunchKernelGGL(decoder_gather_kernel, dim3((unsigned)((T + 255) / 256), B, 2), dim3(256), 0, st, D, s1, s2, B,
                        T, (int)pl.L, g.kernel_size_enc, c->stride, pad_left);
     LAUNCH_CHECK(c, "decoder gather");
@@ -414,7 +465,12 @@ int dptnav_create(const dptnav_config* cfg, dptnav_handle* out) {
   return DPTNAV_OK;
 }
 
-void dptnav_destroy(dptnav_handle h) { delete h; }
+void dptnav_destroy(dptnav_handle h) {
+  if (!h) return;
+  for (ProfRec& r : h->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
+  delete h;
+}
 
 int dptnav_num_weights(dptnav_handle h) { return h ? (int)h->names.size() : 0; }
 const char* dptnav_weight_name(dptnav_handle h, int s) {
@@ -530,6 +586,38 @@ int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* 
   else return h->fail(DPTNAV_ERR_INVALID, "unknown tap '%s'", name);
   return DPTNAV_OK;
 }
+
+// ---- opt-in per-kernel timing (HIP events on the launch stream) --------------------------------
+int dptnav_profile_enable(dptnav_handle h, int on) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  h->prof_on = on != 0;
+  return DPTNAV_OK;
+}
+int dptnav_profile_collect(dptnav_handle h) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  for (ProfRec& r : h->prof_pending) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "profile: %s", hipGetErrorString(e));
+    h->prof_ms[r.cat] += ms;
+    h->prof_n[r.cat] += 1;
+    h->prof_pool.push_back(r.a);
+    h->prof_pool.push_back(r.b);
+  }
+  h->prof_pending.clear();
+  return DPTNAV_OK;
+}
+int dptnav_profile_reset(dptnav_handle h) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (int rc = dptnav_profile_collect(h)) return rc;
+  for (int i = 0; i < CAT_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  return DPTNAV_OK;
+}
+int dptnav_profile_num(void) { return CAT_COUNT; }
+const char* dptnav_profile_name(int i) { return (i >= 0 && i < CAT_COUNT) ? kProfNames[i] : nullptr; }
+double dptnav_profile_ms(dptnav_handle h, int i) { return (h && i >= 0 && i < CAT_COUNT) ? h->prof_ms[i] : -1.0; }
+int64_t dptnav_profile_count(dptnav_handle h, int i) { return (h && i >= 0 && i < CAT_COUNT) ? h->prof_n[i] : -1; }
 
 // Algorithmic cost model (2 FLOP per MAC, GEMM-like terms only) -- SURVEY.md section 8d restated.
 double dptnav_flops_per_mixture(dptnav_handle h, int64_t T) {

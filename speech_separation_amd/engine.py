@@ -128,6 +128,26 @@ class DptnEngine:
     def min_bytes_per_mixture(self, T: int) -> float:
         return float(self.lib.dptnav_min_bytes_per_mixture(self._h, T))
 
+    # ------------------------------------------------------------------ per-kernel device timing
+    def profile(self, on: bool):
+        self.lib.dptnav_profile_enable(self._h, int(on))
+
+    def profile_reset(self):
+        rc = self.lib.dptnav_profile_reset(self._h)
+        if rc:
+            self._raise(rc, "dptnav_profile_reset")
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        """{kernel class: (total device ms, launches)} since the last reset (waits for recorded events)."""
+        rc = self.lib.dptnav_profile_collect(self._h)
+        if rc:
+            self._raise(rc, "dptnav_profile_collect")
+        out = {}
+        for i in range(self.lib.dptnav_profile_num()):
+            out[self.lib.dptnav_profile_name(i).decode()] = (float(self.lib.dptnav_profile_ms(self._h, i)),
+                                                            int(self.lib.dptnav_profile_count(self._h, i)))
+        return out
+
     # ------------------------------------------------------------------ hot path
     def forward(self, mix: torch.Tensor, e1: Optional[torch.Tensor] = None, e2: Optional[torch.Tensor] = None,
                 out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -1,0 +1,94 @@
+"""CPU-side checks: C-ABI surface, checkpoint/shape spec, nn.Module drop-in contract (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from speech_separation_amd import _lib
+from speech_separation_amd.spec import (DPTN_AUDIO, DPTN_AV, DPTN_TINY, DPTNConfig, num_parameters, state_dict_spec,
+                                        synthetic_inputs, synthetic_state_dict)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dptnav.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dptnav_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()                       # raises if the .so is missing or a symbol is absent
+    assert lib.dptnav_abi_version() == _lib.ABI_VERSION
+    assert lib.dptnav_profile_num() == 11
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_path_without_gpu():
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p()
+    cfg = _lib.DptnavConfig(128, 512, 128, 7, 128, 6, 150, 75, 4, 1, 0)
+    assert lib.dptnav_create(C.byref(cfg), C.byref(h)) != 0
+    assert b"no CPU path" in lib.dptnav_last_error(None)
+    from speech_separation_amd.engine import DptnEngine
+    with pytest.raises(RuntimeError):
+        DptnEngine(DPTN_AV, "cpu")
+
+
+def test_spec_matches_reference_checkpoint_surface():
+    spec = state_dict_spec(DPTN_AV)
+    assert len(spec) == 228 and num_parameters(DPTN_AV) == 4_448_194
+    assert num_parameters(DPTN_AUDIO) == 2_797_377                              # paper.tex "2.8 M"
+    keys = [k for k, _ in spec]
+    assert keys[0] == "gate" and keys[1] == "encoder.weight" and keys[-1] == "decoder.weight"
+    assert dict(spec)["dprnn.model.3.inter_chunk_block.mha.in_proj_weight"] == (384, 128)
+    assert dict(spec)["dprnn.model.5.intra_chunk_block.rnn.weight_hh_l0_reverse"] == (512, 128)
+    uni = DPTNConfig(**{**DPTN_AV.to_dict(), "bidir": False})
+    d = dict(state_dict_spec(uni))
+    assert "dprnn.model.0.inter_chunk_block.rnn.weight_ih_l0_reverse" not in d
+    assert "dprnn.model.0.intra_chunk_block.rnn.weight_ih_l0_reverse" in d        # intra is always bidirectional
+    assert d["dprnn.model.0.inter_chunk_block.ffn.1.weight"] == (128, 128)
+    assert d["dprnn.model.0.intra_chunk_block.ffn.1.weight"] == (128, 256)
+
+
+def test_derived_sizes():
+    assert DPTN_AV.frames(32000) == 10665 and DPTN_AV.chunks(10665) == 141
+    assert DPTN_AV.ola_len(141) == 10650 and DPTN_AV.tokens(16, 32000) == 338400
+    assert DPTN_TINY.frames(209) == 68 and DPTN_TINY.chunks(68) == 12
+
+
+def test_synthetic_data_is_deterministic():
+    a, b = synthetic_state_dict(DPTN_TINY, 3), synthetic_state_dict(DPTN_TINY, 3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    i = synthetic_inputs(DPTN_TINY, B=2, T=209, Tv=9)
+    assert np.allclose(i["mix"], i["s1"] + i["s2"]) and i["s1_embedding"].shape == (2, 24, 9)
+
+
+def test_module_is_a_dropin_for_the_reference_class():
+    from speech_separation_amd import DPTNAVWavEncDec, DPTNWavEncDec
+    kw = dict(num_features=128, video_emb_size=512, hidden_video=128, kernel_size_enc=7, hidden_dim=128, num_blocks=6,
+              chunk_size=150, step_size=75, dropout=0.1, num_heads=4, bidir=True)   # src/configs/model/dptn_wav_av.yaml
+    m = DPTNAVWavEncDec(**kw)
+    sd = m.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == state_dict_spec(DPTN_AV)
+    assert str(m).endswith("All parameters: 4448194\nTrainable parameters: 4448194")   # dptn_wav.py:196-207
+    # a reference-format checkpoint loads strictly (base_trainer.py:557-560 accepts raw or wrapped dicts)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(DPTN_AV, 1).items()}, strict=True)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    # compute is GPU-only: a CPU call must raise, never fall back
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU"):
+        m(mix=torch.zeros(1, 32000), s1_embedding=torch.zeros(1, 512, 50), s2_embedding=torch.zeros(1, 512, 50))
+    a = DPTNWavEncDec(num_features=64, kernel_size_enc=7, hidden_dim=128, num_blocks=6, chunk_size=150, step_size=75,
+                      num_heads=4, dropout=0.1, bidir=True)                            # dptn_wav.yaml
+    assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == state_dict_spec(DPTN_AUDIO)
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "speech_separation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|oracle[./](dptn_oracle|torch_stock)|import_module\(.oracle",
+                                     src, flags=re.M), f"{f} reaches into oracle/"

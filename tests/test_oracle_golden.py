@@ -78,3 +78,28 @@ def test_real_feature_sizes_match_reference(golden, name):
     d = abs(O.si_snri_metric(out["s1_pred"], out["s2_pred"], inp["s1"], inp["s2"], inp["mix"])
             - O.si_snri_metric(z["tap.s1_pred"], z["tap.s2_pred"], inp["s1"], inp["s2"], inp["mix"]))
     assert d < 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_unidir"])
+def test_stock_torch_composition_matches_reference(golden, name):
+    """oracle/torch_stock.py (the cpu_baseline 'port') reproduces the reference outputs."""
+    import torch
+    from oracle.torch_stock import StockDPTN
+    cfg, z = golden(name)
+    w, inp, ref = _split(z)
+    model = StockDPTN(cfg, w)
+    out = model(**{k: torch.from_numpy(v) for k, v in inp.items()})
+    for k in ("s1_pred", "s2_pred"):
+        assert O.agreement_db(out[k].numpy(), ref[k]) > 100, k
+
+
+def test_stock_torch_composition_real_sizes(golden):
+    import torch
+    from oracle.torch_stock import StockDPTN
+    cfg, z = golden("mid_av")
+    B, T, Tv = (int(v) for v in z["shape"])
+    sd = synthetic_state_dict(cfg, seed=0)
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=123)
+    out = StockDPTN(cfg, sd)(**{k: torch.from_numpy(v) for k, v in inp.items()})
+    for k in ("s1_pred", "s2_pred"):
+        assert O.agreement_db(out[k].numpy(), z["tap." + k]) > 100, k
