@@ -40,19 +40,39 @@ T_SAMPLES = 32000              # "4 s @ 8 kHz"
 BATCH_PER_GPU = 16
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def log(msg: str):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
     """Reference CPU path (stock PyTorch operators, all host cores), bounded sample: max mixtures/s over
     B in {1, 4} (CPU throughput falls with B)."""
     from oracle.torch_stock import StockDPTN
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline on {cores} host threads")
     model = StockDPTN(cfg, sd)
     best, parts = 0.0, []
     t_start = time.perf_counter()
     for B, reps in ((1, 5), (4, 2)):
         inp = synthetic_inputs(cfg, B=B, T=T_SAMPLES, Tv=50, seed=123)
         t = {k: torch.from_numpy(v) for k, v in inp.items()}
+        if parts and time.perf_counter() - t_start > 0.4 * seconds_budget:
+            break  # not enough budget left for the larger batch
         model(**t)  # warm-up
+        log(f"cpu_baseline B={B} warm-up done at {time.perf_counter() - t_start:.1f} s")
         done, t0 = 0, time.perf_counter()
         for _ in range(reps):
             model(**t)
@@ -94,6 +114,7 @@ def main():
     e2 = torch.from_numpy(inp["s2_embedding"]).to(dev)
     out = (torch.empty_like(mix), torch.empty_like(mix))
 
+    log(f"rank {env.rank}/{env.world} on {dev}: warm-up")
     for _ in range(args.warmup):
         eng.forward(mix, e1, e2, out=out)
     env.barrier()
@@ -105,6 +126,7 @@ def main():
     env.barrier()
     torch.cuda.synchronize(dev)
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
 
     # ---- per-kernel device time: HIP events on the launch stream, same workload, separate pass ----------
     eng.profile(True)

@@ -62,6 +62,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; import it FIRST so that libdptnav resolves libamdhip64 to the
+    # runtime torch already loaded -- device pointers and hipStream_t handles are only meaningful inside
+    # one runtime instance.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
