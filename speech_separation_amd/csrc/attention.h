@@ -25,7 +25,7 @@ struct AttnShape {
 };
 
 template <int DH, int NKB>
-__global__ __launch_bounds__(64 * NKB) void attention_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_kernel(const float* __restrict__ qkv,
                                                               float* __restrict__ out, int N, SeqGeom g,
                                                               float scale_log2e) {
   using Sh = AttnShape<DH>;

@@ -70,6 +70,7 @@ struct dptnav_ctx {
   std::string err;
   int stride;
   int dh;
+  int num_cus = 256;
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -258,7 +259,11 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
                     hipStream_t st) {
   auto kern = attention_kernel<DH, NKB>;
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
-  if (int rc = set_lds(c, kern, lds, "attention")) return rc;
+  static bool ready = false;
+  if (!ready) {
+    if (int rc = set_lds(c, kern, lds, "attention")) return rc;
+    ready = true;
+  }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
   hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale);
@@ -281,14 +286,25 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 }
 
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
+// The engine is persistent (grid-stride over tiles, weights loaded once per workgroup), so the grid is
+// sized to what is co-resident: CUs x blocks/CU from the occupancy query, queried once per instantiation.
 template <int KIN, int NT, int WR, int WC, class AL, class EP>
-int launch_gemm(dptnav_ctx* c, int cat, const char* what, const float* W, int64_t ntiles, int colgroups, int cap,
+int launch_gemm(dptnav_ctx* c, int cat, const char* what, const float* W, int64_t ntiles, int colgroups, int /*cap*/,
                 const AL& al, const EP& ep, hipStream_t st, const float* Walt = nullptr) {
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
-  if (int rc = set_lds(c, kern, lds, what)) return rc;
+  static int resident = 0;  // per instantiation
+  if (resident == 0) {
+    if (int rc = set_lds(c, kern, lds, what)) return rc;
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds);
+    if (e != hipSuccess || per_cu < 1) return c->fail(DPTNAV_ERR_HIP, "%s: occupancy query: %s", what, hipGetErrorString(e));
+    resident = per_cu * c->num_cus;
+  }
+  int gx = resident / colgroups;
+  if (gx < 1) gx = 1;
   ProfScope ps(c, cat, st);
-  hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, cap), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
+  hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
                      al, ep);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
@@ -360,7 +376,7 @@ int run_head(dptnav_ctx* c, const float* mix, const float* e1, const float* e2, 
   if (!g.audio_only) {
     float* v = ws + pl.vid;
     ProfScope ps(c, CAT_VIDEO, st);
-    hipLaunchKernelGGL(video_linear_kernel, dim3(B, 2), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
+    hipLaunchKernelGGL(video_linear_kernel, dim3(2 * B, g.hidden_video / 8), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
                        c->w("visual_compression.bias"), v, g.video_emb_size, Tv, g.hidden_video / 2);
     LAUNCH_CHECK(c, "video linear");
     vid = v;
@@ -460,6 +476,13 @@ int dptnav_create(const dptnav_config* cfg, dptnav_handle* out) {
   c->cfg = *cfg;
   c->stride = cfg->kernel_size_enc / 2;
   c->dh = cfg->num_features / cfg->num_heads;
+  {
+    int devid = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      c->num_cus = prop.multiProcessorCount;
+  }
   build_names(c);
   *out = c;
   return DPTNAV_OK;

@@ -27,7 +27,7 @@ struct GemmShape {
   static constexpr int LDC = WGCOLS + 4;
   static constexpr int KS = KIN / 2;       // MFMA k-steps
   static constexpr size_t lds_bytes(bool direct) {
-    return sizeof(float) * ((size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
+    return sizeof(float) * (2 * (size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
   }
 };
 
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   static_assert(WR * WC == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Cs = smem + Sh::BM * Sh::LDA;
+  float* Cs = smem + 2 * Sh::BM * Sh::LDA;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
@@ -68,24 +68,56 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   constexpr int K4 = KIN / 4;                       // float4 per A row
   constexpr int NLD = (Sh::BM * K4) / 256;          // float4 loads per thread per tile
   static_assert((Sh::BM * K4) % 256 == 0, "tile/threads");
+  constexpr int C4 = Sh::WGCOLS / 4;                // float4 per C row
+  constexpr int NPASS = Epi::DIRECT ? 1 : (Sh::BM * C4) / 256;
+  static_assert(Epi::DIRECT || (Sh::BM * C4) % 256 == 0, "epilogue mapping");
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- stage the A tile (coalesced: consecutive lanes = consecutive float4 of a row) --------
+  // Software pipeline: the A tile of iteration i+1 is fetched into registers while iteration i computes;
+  // As is double buffered, so one barrier orders "tile written" -> "fragments read" and nothing else is needed
+  // for As (a buffer is rewritten two iterations later, behind the next iteration's barrier).
+  float4 pf[NLD];
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
-      const int row = idx / K4, k4 = idx % K4;
-      const float4 v = aload.load4(tile, row, k4);
-      *reinterpret_cast<float4*>(&As[row * Sh::LDA + 4 * k4]) = v;
+      pf[i] = aload.load4(tile, idx / K4, idx % K4);
     }
-    __syncthreads();
+  }
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    float* Ab = As + buf * (Sh::BM * Sh::LDA);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
+    }
+    __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
+
+    const int next = tile + gridDim.x;
+    if (next < ntiles) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int idx = i * 256 + tid;
+        pf[i] = aload.load4(next, idx / K4, idx % K4);
+      }
+    }
+    // epilogue operands that do not depend on the product (residual rows ...) are requested now as well
+    float4 epf[NPASS];
+    if constexpr (!Epi::DIRECT) {
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        const int idx = p * 256 + tid;
+        epf[p] = epi.prefetch(tile, idx / C4, idx % C4);
+      }
+    }
 
     // ---- A fragments + MFMA --------------------------------------------------------------------
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
     {
-      const float* arow = &As[(wr * 32 + c) * Sh::LDA + 4 * hh];
+      const float* arow = &Ab[(wr * 32 + c) * Sh::LDA + 4 * hh];
 #pragma unroll
       for (int m = 0; m < KIN / 8; ++m) {
         const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
@@ -102,7 +134,6 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     if constexpr (Epi::DIRECT) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
-      __syncthreads();  // As is rewritten by the next tile
     } else {
       // ---- C tile -> LDS (each half-wave writes 128 B contiguous), then row-space epilogue ------
 #pragma unroll
@@ -112,18 +143,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) Cs[(wr * 32 + ROW32(r, hh)) * Sh::LDC + col] = acc[nt][r];
       }
       __syncthreads();
-      constexpr int C4 = Sh::WGCOLS / 4;              // float4 per C row
-      constexpr int NPASS = (Sh::BM * C4) / 256;
-      static_assert((Sh::BM * C4) % 256 == 0, "epilogue mapping");
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const int idx = p * 256 + tid;
         const int row = idx / C4, c4 = idx % C4;
         const float4 v = *reinterpret_cast<const float4*>(&Cs[row * Sh::LDC + 4 * c4]);
-        epi.row(tile, row, colgroup, c4, v);
+        epi.row(tile, row, colgroup, c4, v, epf[p]);
       }
-      // next iteration's first barrier orders these Cs reads before the next Cs writes; As is
-      // only rewritten after every wave passed the barrier above (fragments already in registers)
     }
   }
 }
@@ -190,7 +216,8 @@ struct EpiBiasStore {
   int ldo;
   int bm;
   int wgcols;
-  DEV void row(int tile, int row, int colgroup, int c4, float4 v) const {
+  DEV float4 prefetch(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 /*pre*/) const {
     const int64_t r = (int64_t)tile * bm + row;
     if (r >= M) return;
     const int col = colgroup * wgcols + 4 * c4;
@@ -212,11 +239,14 @@ struct EpiBiasResLN {
   int64_t M;
   int ld;
   int bm;
-  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v) const {
+  DEV float4 prefetch(int tile, int row, int c4) const {   // the residual row: independent of the product
+    const int64_t r = (int64_t)tile * bm + row;
+    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) const {
     const int64_t r = (int64_t)tile * bm + row;
     const bool ok = r < M;
     const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    float4 x = ok ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
     float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll

@@ -9,19 +9,28 @@
 // video branch, step 1: Linear(Cv -> HV/2) for both speakers (shared weights), concatenated
 //   reference: dptn_wav.py:173-179.   e* (B,Cv,Tv) -> vid (B,Tv,HV)
 // ------------------------------------------------------------------------------------------------
+//   grid (B*2, half/4), block 256 = 4 output features x 64 frame slots: the weight is wave-uniform, the
+//   embedding read is coalesced over frames.
 __global__ __launch_bounds__(256) void video_linear_kernel(const float* __restrict__ e1,
                                                             const float* __restrict__ e2,
                                                             const float* __restrict__ W,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ vid, int Cv, int Tv, int half) {
-  const int b = blockIdx.x, spk = blockIdx.y;
+  const int b = blockIdx.x >> 1, spk = blockIdx.x & 1;
+  const int o = blockIdx.y * 4 + (threadIdx.x >> 6);
   const float* e = (spk ? e2 : e1) + (int64_t)b * Cv * Tv;
-  for (int idx = threadIdx.x; idx < half * Tv; idx += blockDim.x) {
-    const int o = idx / Tv, t = idx - o * Tv;
-    const float* w = W + (int64_t)o * Cv;
-    float acc = 0.f;
-    for (int cc = 0; cc < Cv; ++cc) acc = fmaf(w[cc], e[(int64_t)cc * Tv + t], acc);
-    vid[((int64_t)b * Tv + t) * (2 * half) + spk * half + o] = acc + bias[o];
+  const float* w = W + (int64_t)o * Cv;
+  for (int t = threadIdx.x & 63; t < Tv; t += 64) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int cc = 0;
+    for (; cc + 4 <= Cv; cc += 4) {
+      a0 = fmaf(w[cc + 0], e[(int64_t)(cc + 0) * Tv + t], a0);
+      a1 = fmaf(w[cc + 1], e[(int64_t)(cc + 1) * Tv + t], a1);
+      a2 = fmaf(w[cc + 2], e[(int64_t)(cc + 2) * Tv + t], a2);
+      a3 = fmaf(w[cc + 3], e[(int64_t)(cc + 3) * Tv + t], a3);
+    }
+    for (; cc < Cv; ++cc) a0 = fmaf(w[cc], e[(int64_t)cc * Tv + t], a0);
+    vid[((int64_t)b * Tv + t) * (2 * half) + spk * half + o] = ((a0 + a1) + (a2 + a3)) + bias[o];
   }
 }
 
@@ -136,12 +145,15 @@ struct EpiSkipDecoderTaps {
   const float* wdec;   // (N,1,k)
   int64_t BL;          // B*L
   int kenc, bm;
-  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v) const {
+  DEV float4 prefetch(int tile, int row, int c4) const {   // fused latent row of this frame (skip connection)
+    const int64_t r = (int64_t)tile * bm + row;
+    const int64_t e = r < 2 * BL ? (r % BL) : 0;
+    return *reinterpret_cast<const float4*>(E + e * (4 * GROUP) + 4 * c4);
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) const {
     const int64_t r = (int64_t)tile * bm + row;
     const bool ok = r < 2 * BL;
-    const int64_t e = ok ? (r % BL) : 0;
     const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    const float4 x = *reinterpret_cast<const float4*>(E + e * (4 * GROUP) + 4 * c4);
     v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
     float mine = 0.f;
     for (int j = 0; j < kenc; ++j) {
