@@ -42,22 +42,24 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   const int ld = 3 * N;
   const float* base = qkv + head * DH;
 
-  // ---- stage K and V ----------------------------------------------------------------------------
-  constexpr int R4 = DH / 4;  // float4 per row
-  for (int idx = tid; idx < NKB * 32 * R4; idx += 64 * NKB) {
+  // ---- issue EVERY global load first (K, V staging rows and the Q fragment), then store to LDS ----
+  constexpr int R4 = DH / 4;                        // float4 per row
+  constexpr int NST = (32 * R4) / 64;               // staging float4 per thread for K (and for V)
+  static_assert((32 * R4) % 64 == 0, "staging map");
+  float4 kreg[NST], vreg[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = i * (64 * NKB) + tid;
     const int p = idx / R4, f = idx % R4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    vreg[i] = kreg[i];
     if (p < len) {
       const float* row = base + (tok0 + (int64_t)p * tstride) * ld + 4 * f;
-      kv = *reinterpret_cast<const float4*>(row + N);
-      vv = *reinterpret_cast<const float4*>(row + 2 * N);
+      kreg[i] = *reinterpret_cast<const float4*>(row + N);
+      vreg[i] = *reinterpret_cast<const float4*>(row + 2 * N);
     }
-    *reinterpret_cast<float4*>(&Ks[p * Sh::LDK + 4 * f]) = kv;
-    *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 4 * f]) = vv;
-    if (DH == 16) *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 16 + 4 * f]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-
-  // ---- Q fragments (B operand), pre-scaled by log2(e)/sqrt(dh) ----------------------------------
+  // Q fragments (B operand), pre-scaled by log2(e)/sqrt(dh)
   float qf[DH / 2];
   {
     const int p = qb * 32 + c;
@@ -71,6 +73,14 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       qf[4 * m + 2] = v.z * scale_log2e;
       qf[4 * m + 3] = v.w * scale_log2e;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = i * (64 * NKB) + tid;
+    const int p = idx / R4, f = idx % R4;
+    *reinterpret_cast<float4*>(&Ks[p * Sh::LDK + 4 * f]) = kreg[i];
+    *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 4 * f]) = vreg[i];
+    if (DH == 16) *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 16 + 4 * f]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
 
@@ -90,39 +100,39 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     }
   }
 
-  // ---- softmax over keys (per query = per lane column) ------------------------------------------
+  // ---- softmax over keys (per query = per lane column); only the last key block can hold padding ----
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((NKB - 1) * 32 + ROW32(r, hh) >= len) s[NKB - 1][r] = -1e30f;
   float mx = -1e30f;
 #pragma unroll
   for (int rb = 0; rb < NKB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = rb * 32 + ROW32(r, hh);
-      const float v = key < len ? s[rb][r] : -1e30f;
-      s[rb][r] = v;
-      mx = fmaxf(mx, v);
-    }
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[rb][r]);
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
 #pragma unroll
   for (int rb = 0; rb < NKB; ++rb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = exp2f(s[rb][r] - mx);
+      const float e = fast_exp2(s[rb][r] - mx);
       s[rb][r] = e;
       sum += e;
     }
   sum += __shfl_xor(sum, 32);
-  const float inv = 1.0f / sum;
+  const float inv = fast_rcp(sum);
 
-  // ---- O = P V ----------------------------------------------------------------------------------
+  // ---- O = P V: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them ----
   f32x16 o = zero16();
+  const float* vcol = Vs + (4 * hh) * Sh::LDV + c;
 #pragma unroll
-  for (int rb = 0; rb < NKB; ++rb)
+  for (int rb = 0; rb < NKB; ++rb) {
+    float vv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = Vs[(rb * 32 + ROW32(r, hh)) * Sh::LDV + c];
-      o = mfma32(s[rb][r], v, o);
-    }
+    for (int r = 0; r < 16; ++r) vv[r] = vcol[(rb * 32 + (r & 3) + 8 * (r >> 2)) * Sh::LDV];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o = mfma32(s[rb][r], vv[r], o);
+  }
 
   // ---- normalise and store: reg r of lane (c,hh) is O[query ROW32(r,hh)][d = c] -----------------
 #pragma unroll

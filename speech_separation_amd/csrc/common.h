@@ -30,9 +30,19 @@ DEV f32x16 zero16() {
   return z;
 }
 
-DEV float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 directly (1 ulp each): sigma(x) = 1/(1+2^(-x log2 e)).  __frcp_rn / expf would expand
+// to ~10-instruction IEEE sequences, which showed up as 40 % of the LSTM step's VALU work.
+DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
 // 2/(1+e^-2x) - 1 : saturates correctly to +-1 (no inf/inf)
-DEV float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+DEV float fast_tanh(float x) { return fmaf(2.0f, fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * x)), -1.0f); }
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to wave-uniform LDS base + lane*16 (no VGPR hop).
+DEV void glds16(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 // Sequence geometry of one TransformerDPRNN call over the token tensor x[b][s][k][n].
 //   mode 0 (intra-chunk): sequence q = b*S + s, position t = k   -> token q*K + t

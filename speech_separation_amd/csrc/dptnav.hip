@@ -230,7 +230,7 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->y1 = take(p->y1_n);
   p->pre = take((size_t)2 * pre_tiles * 512 * 32);
   p->hc_n = (size_t)p->M * 2 * H;
-  p->hc = take(p->hc_n);
+  p->hc = take(p->hc_n + 2 * H);   // + one dump row for padded sequences
   p->total = o;
   return DPTNAV_OK;
 }
@@ -351,7 +351,7 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
     if (int rc = set_lds(c, lstm_recurrence_kernel, LSTM_LDS_BYTES, "lstm")) return rc;
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(lstm_recurrence_kernel, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0],
-                       w.w_hh[1], hc, w.ndir * LSTM_H, geom);
+                       w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
     LAUNCH_CHECK(c, "lstm");
   }
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)

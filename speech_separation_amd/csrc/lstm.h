@@ -19,17 +19,23 @@
 
 constexpr int LSTM_H = 128;
 constexpr int LSTM_LDH = LSTM_H + 4;
-constexpr size_t LSTM_LDS_BYTES = sizeof(float) * 2 * 32 * LSTM_LDH;
+constexpr int LSTM_HS_FLOATS = 2 * 32 * LSTM_LDH;          // h double buffer
+constexpr int LSTM_PRE_FLOATS = 4 * 16 * 256;               // one step of pre-activations: [wave][gate*4+q][lane][4]
+constexpr size_t LSTM_LDS_BYTES = sizeof(float) * (LSTM_HS_FLOATS + LSTM_PRE_FLOATS);
 
+// hc has one extra "dump" row at index M (rows of padded sequences are written there, branch-free).
 __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __restrict__ pre,
                                                                const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b,
-                                                               float* __restrict__ hc, int ldh, SeqGeom g) {
+                                                               float* __restrict__ hc, int ldh, int dump_row,
+                                                               SeqGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hs = smem;  // [2][32][LSTM_LDH]
+  float* Hs = smem;                      // [2][32][LSTM_LDH]
+  float* Ps = smem + LSTM_HS_FLOATS;     // [4 waves][16 pieces][64 lanes][4]
 
   const int tid = threadIdx.x;
-  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
   const int st = blockIdx.x, d = blockIdx.y;
   const float* whh = d ? whh_b : whh_f;
 
@@ -48,43 +54,72 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
     }
   }
 
-  // ---- per-lane output rows: token offset of (sequence rho, t=0) or -1 -----------------------
-  int tokbase[16];
+  // ---- per-lane output element index of (row rho, this step) in hc, advanced by a uniform stride ----
+  const int outcol = d * LSTM_H + 32 * w + c;
+  const int t0 = d ? g.len - 1 : 0;
+  const int tdir = d ? -1 : 1;
+  const int tstride = seq_token_stride(g);
+  unsigned oidx[16];
+  unsigned ostep[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int q = st * 32 + ROW32(r, hh);
-    tokbase[r] = q < g.nseq ? (int)seq_token_base(g, q) : -1;
+    const bool ok = q < g.nseq;
+    oidx[r] = ok ? (unsigned)(((int)seq_token_base(g, q) + t0 * tstride) * ldh + outcol)
+                 : (unsigned)(dump_row * ldh + outcol);
+    ostep[r] = ok ? (unsigned)(tdir * tstride * ldh) : 0u;
   }
-  const int tstride = seq_token_stride(g);
 
   for (int i = tid; i < 32 * LSTM_LDH; i += 256) Hs[i] = 0.f;  // h_{-1} = 0 (buffer 0)
   f32x16 cst = zero16();
+
+  // pre-activation stream: wave w owns pieces (gate gi, quarter q) = column block gi*4+w, 1 KiB each
+  const float* pre_lane = pre + pre_tile_offset(d, st, 0, g.nst, g.len) + (int64_t)w * 1024 + lane * 4;
+  float* ps_wave = Ps + w * (16 * 256);
+  auto issue_pre = [&](int t) {
+    const float* p = pre_lane + (int64_t)t * (512 * 32);
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) glds16(p + gi * 4096 + q * 256, ps_wave + (gi * 4 + q) * 256);
+  };
+  issue_pre(t0);
   __syncthreads();
 
-  const float* pre_tile0 = pre + pre_tile_offset(d, st, 0, g.nst, g.len) + hh * 128 + c * 4;
-  const int outcol = d * LSTM_H + 32 * w + c;
+  // ReLU(h) of the PREVIOUS step is stored at the top of the next one, right behind the DMA issue: vmcnt counts
+  // stores too, so storing just before the end-of-step barrier would make every step wait for store retirement.
+  float hout[16];
+  auto store_prev = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      hc[oidx[r]] = hout[r];
+      oidx[r] += ostep[r];
+    }
+  };
 
   for (int step = 0; step < g.len; ++step) {
-    const int t = d ? g.len - 1 - step : step;
+    const int t = t0 + tdir * step;
     const float* hcur = Hs + (step & 1) * 32 * LSTM_LDH;
     float* hnext = Hs + ((step + 1) & 1) * 32 * LSTM_LDH;
 
-    // accumulators start from the pre-activations
+    // accumulators start from the pre-activations that the LDS-DMA delivered during the previous step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x16 acc[4];
-    {
-      const float* p = pre_tile0 + (int64_t)t * (512 * 32);
 #pragma unroll
-      for (int gi = 0; gi < 4; ++gi) {
+    for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(p + (gi * 4 + w) * 1024 + q * 256);
-          acc[gi][4 * q + 0] = v.x;
-          acc[gi][4 * q + 1] = v.y;
-          acc[gi][4 * q + 2] = v.z;
-          acc[gi][4 * q + 3] = v.w;
-        }
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(ps_wave + (gi * 4 + q) * 256 + lane * 4);
+        acc[gi][4 * q + 0] = v.x;
+        acc[gi][4 * q + 1] = v.y;
+        acc[gi][4 * q + 2] = v.z;
+        acc[gi][4 * q + 3] = v.w;
       }
-    }
+    // the wave's own LDS region may only be refilled once these reads have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (step + 1 < g.len) issue_pre(t + tdir);
+    if (step > 0) store_prev();
+
     // h_{t-1} W_hh^T
     {
       const float* arow = hcur + c * LSTM_LDH + 4 * hh;
@@ -107,12 +142,13 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
       const float fg = fast_sigmoid(acc[1][r]);
       const float gg = fast_tanh(acc[2][r]);
       const float og = fast_sigmoid(acc[3][r]);
-      const float cn = fg * cst[r] + ig * gg;
+      const float cn = fmaf(fg, cst[r], ig * gg);
       cst[r] = cn;
       const float hn = og * fast_tanh(cn);
       hnext[ROW32(r, hh) * LSTM_LDH + 32 * w + c] = hn;
-      if (tokbase[r] >= 0) hc[(int64_t)(tokbase[r] + t * tstride) * ldh + outcol] = fmaxf(hn, 0.f);
+      hout[r] = fmaxf(hn, 0.f);
     }
     __syncthreads();
   }
+  store_prev();
 }
