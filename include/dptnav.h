@@ -122,6 +122,11 @@ int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int
  * [ReLU(h_fwd|h_bwd)].  Returns non-zero for an unknown name. */
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* offset_bytes,
                          size_t* numel);
+/* Tuning / diagnostic knobs (never needed for correct results).  Keys:
+ *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
+ *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
+int dptnav_set_option(dptnav_handle h, const char* key, int value);
+
 /* Opt-in per-kernel timing: while enabled every launch is bracketed by two hipEvents recorded on the
  * launch stream (so the figures are device time of that kernel, not host time).  collect() waits for
  * the recorded events and accumulates them per kernel class; ms()/count() read the accumulators.

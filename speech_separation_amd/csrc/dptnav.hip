@@ -15,6 +15,7 @@
 #include "gemm_ws.h"
 #include "headtail.h"
 #include "lstm.h"
+#include "lstm_pp.h"
 
 namespace {
 
@@ -29,7 +30,7 @@ struct PathWeights {
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t vid, E, X0, X1, qkv, att, y1, pre, hc, total;
+  size_t vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -49,6 +50,7 @@ struct ProfRec {
 struct dptnav_ctx {
   dptnav_config cfg;
   bool prof_on = false;
+  bool opt_lstm_stamps = false;
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[CAT_COUNT] = {0};
@@ -230,7 +232,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->y1 = take(p->y1_n);
   p->pre = take((size_t)2 * pre_tiles * 512 * 32);
   p->hc_n = (size_t)p->M * 2 * H;
-  p->hc = take(p->hc_n + 2 * H);   // + one dump row for padded sequences
+  p->hc = take(p->hc_n + (size_t)p->S * g.chunk_size * 2 * H);   // + dump rows for padded sequences
+  p->stamps = take((size_t)2 * 2 * (nst_a > nst_e ? nst_a : nst_e) * 4 * 4 * 2);   // u64 [dir][tile][wave][4]
   p->total = o;
   return DPTNAV_OK;
 }
@@ -348,10 +351,13 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
   }
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
   {
-    if (int rc = set_lds(c, lstm_recurrence_kernel, LSTM_LDS_BYTES, "lstm")) return rc;
+    auto kern = c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>;
+    if (int rc = set_lds(c, kern, LSTM_LDS_BYTES, "lstm")) return rc;
+    // diagnostic stamps land behind the dump rows of hc (see make_plan)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
     ProfScope ps(c, CAT_LSTM, st);
-    hipLaunchKernelGGL(lstm_recurrence_kernel, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0],
-                       w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
+    hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
+                       w.ndir * LSTM_H, (int)M, geom, stamps);
     LAUNCH_CHECK(c, "lstm");
   }
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
@@ -606,7 +612,17 @@ int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* 
   else if (n == "y1") { *off = pl.y1 * 4; *numel = pl.y1_n; }
   else if (n == "hc") { *off = pl.hc * 4; *numel = pl.hc_n; }
   else if (n == "encoded") { *off = pl.E * 4; *numel = (size_t)B * pl.L * h->cfg.num_features; }
+  else if (n == "lstm_stamps") { *off = pl.stamps * 4; *numel = (pl.total - pl.stamps); }
   else return h->fail(DPTNAV_ERR_INVALID, "unknown tap '%s'", name);
+  return DPTNAV_OK;
+}
+
+// ---- tuning / diagnostic knobs ----------------------------------------------------------------------
+int dptnav_set_option(dptnav_handle h, const char* key, int value) {
+  if (!h || !key) return DPTNAV_ERR_INVALID;
+  const std::string k(key);
+  if (k == "lstm_stamps") h->opt_lstm_stamps = value != 0;
+  else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }
 

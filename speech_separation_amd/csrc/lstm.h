@@ -24,11 +24,14 @@ constexpr int LSTM_PRE_FLOATS = 4 * 16 * 256;               // one step of pre-a
 constexpr size_t LSTM_LDS_BYTES = sizeof(float) * (LSTM_HS_FLOATS + LSTM_PRE_FLOATS);
 
 // hc has one extra "dump" row at index M (rows of padded sequences are written there, branch-free).
+// STAMP = true is a diagnostic build: per-wave s_memtime sums of the step's segments are written to `stamps`
+// ([workgroup][wave][4] cycles: acc-init, MFMA, cell, barrier); its run time is not representative.
+template <bool STAMP>
 __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __restrict__ pre,
                                                                const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b,
                                                                float* __restrict__ hc, int ldh, int dump_row,
-                                                               SeqGeom g) {
+                                                               SeqGeom g, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                      // [2][32][LSTM_LDH]
   float* Ps = smem + LSTM_HS_FLOATS;     // [4 waves][16 pieces][64 lanes][4]
@@ -59,15 +62,14 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
   const int t0 = d ? g.len - 1 : 0;
   const int tdir = d ? -1 : 1;
   const int tstride = seq_token_stride(g);
+  // (rows of padded sequences walk through the dump rows [dump_row, dump_row + S*K) with the same stride)
   unsigned oidx[16];
-  unsigned ostep[16];
+  const unsigned ostep = (unsigned)(tdir * tstride * ldh);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int q = st * 32 + ROW32(r, hh);
-    const bool ok = q < g.nseq;
-    oidx[r] = ok ? (unsigned)(((int)seq_token_base(g, q) + t0 * tstride) * ldh + outcol)
-                 : (unsigned)(dump_row * ldh + outcol);
-    ostep[r] = ok ? (unsigned)(tdir * tstride * ldh) : 0u;
+    const int tokb = q < g.nseq ? (int)seq_token_base(g, q) : dump_row;
+    oidx[r] = (unsigned)((tokb + t0 * tstride) * ldh + outcol);
   }
 
   for (int i = tid; i < 32 * LSTM_LDH; i += 256) Hs[i] = 0.f;  // h_{-1} = 0 (buffer 0)
@@ -86,18 +88,23 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
   issue_pre(t0);
   __syncthreads();
 
-  // ReLU(h) of the PREVIOUS step is stored at the top of the next one, right behind the DMA issue: vmcnt counts
-  // stores too, so storing just before the end-of-step barrier would make every step wait for store retirement.
+  // ReLU(h) of the PREVIOUS step is stored during the next step's MFMA block: vmcnt counts stores too, so storing
+  // just before the end-of-step barrier would make every step wait for store retirement.
   float hout[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hout[r] = 0.f;   // step 0 stores these zeros at position t0; step 1 overwrites them
   auto store_prev = [&]() {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       hc[oidx[r]] = hout[r];
-      oidx[r] += ostep[r];
+      oidx[r] += ostep;
     }
   };
 
+  unsigned long long seg[4] = {0, 0, 0, 0};
   for (int step = 0; step < g.len; ++step) {
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (STAMP) c0 = __builtin_amdgcn_s_memtime();
     const int t = t0 + tdir * step;
     const float* hcur = Hs + (step & 1) * 32 * LSTM_LDH;
     float* hnext = Hs + ((step + 1) & 1) * 32 * LSTM_LDH;
@@ -115,25 +122,42 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
         acc[gi][4 * q + 2] = v.z;
         acc[gi][4 * q + 3] = v.w;
       }
+    // the whole A operand (h_{t-1}, 32 x 128) is fetched in one batch as well: a prefetch placed inside the MFMA
+    // block gets an s_waitcnt lgkmcnt(0) right behind it and exposes one LDS round trip per k-chunk
+    const float* arow = hcur + c * LSTM_LDH + 4 * hh;
+    float4 afr[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 8 * m);
     // the wave's own LDS region may only be refilled once these reads have returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (step + 1 < g.len) issue_pre(t + tdir);
-    if (step > 0) store_prev();
+    if (STAMP) c1 = __builtin_amdgcn_s_memtime();
 
-    // h_{t-1} W_hh^T
-    {
-      const float* arow = hcur + c * LSTM_LDH + 4 * hh;
+    // h_{t-1} W_hh^T: 64 pinned groups of 4 MFMAs.  The step's side work rides in the MFMA shadow, one item per
+    // group: slots 0..15 issue the LDS-DMA of the NEXT step's pre-activations (the LDS copy was consumed above),
+    // slots 16..31 store ReLU(h) of the PREVIOUS step.
+    // branch-free: the last step re-requests its own tile, step 0 stores zeros without advancing
+    const float* pnext = pre_lane + (int64_t)(step + 1 < g.len ? t + tdir : t) * (512 * 32);
+    const unsigned adv = step > 0 ? ostep : 0u;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
+    for (int m = 0; m < 16; ++m) {
+      const float av[4] = {afr[m].x, afr[m].y, afr[m].z, afr[m].w};
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-          acc[gi] = mfma32(a.x, wf[gi][4 * m + 0], acc[gi]);
-          acc[gi] = mfma32(a.y, wf[gi][4 * m + 1], acc[gi]);
-          acc[gi] = mfma32(a.z, wf[gi][4 * m + 2], acc[gi]);
-          acc[gi] = mfma32(a.w, wf[gi][4 * m + 3], acc[gi]);
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) acc[gi] = mfma32(av[tt], wf[gi][4 * m + tt], acc[gi]);
+        const int slot = 4 * m + tt;
+        if (slot < 16) {
+          glds16(pnext + (slot >> 2) * 4096 + (slot & 3) * 256, ps_wave + slot * 256);
+        } else if (slot < 32) {
+          hc[oidx[slot - 16]] = hout[slot - 16];
+          oidx[slot - 16] += adv;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (STAMP) {
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::"v"(acc[0][0]), "v"(acc[3][15]));
+      c2 = __builtin_amdgcn_s_memtime();
     }
     // cell update (lane-local) + publish h_t
 #pragma unroll
@@ -148,7 +172,19 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
       hnext[ROW32(r, hh) * LSTM_LDH + 32 * w + c] = hn;
       hout[r] = fmaxf(hn, 0.f);
     }
+    if (STAMP) c3 = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (STAMP) {
+      const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+      seg[0] += c1 - c0;
+      seg[1] += c2 - c1;
+      seg[2] += c3 - c2;
+      seg[3] += c4 - c3;
+    }
   }
   store_prev();
+  if (STAMP && lane == 0) {
+    unsigned long long* o = stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 4;
+    o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3];
+  }
 }

@@ -128,6 +128,11 @@ class DptnEngine:
     def min_bytes_per_mixture(self, T: int) -> float:
         return float(self.lib.dptnav_min_bytes_per_mixture(self._h, T))
 
+    def set_option(self, key: str, value: int):
+        rc = self.lib.dptnav_set_option(self._h, key.encode(), int(value))
+        if rc:
+            self._raise(rc, "dptnav_set_option")
+
     # ------------------------------------------------------------------ per-kernel device timing
     def profile(self, on: bool):
         self.lib.dptnav_profile_enable(self._h, int(on))

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-segment cycle shares of one LSTM step, from the STAMP build of the kernel."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speech_separation_amd.engine import DptnEngine, params_to_device  # noqa: E402
+from speech_separation_amd.spec import DPTN_AV, synthetic_state_dict  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = DPTN_AV
+eng = DptnEngine(cfg, dev)
+eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
+B, T = 16, 32000
+S = eng.chunks(T)
+x = torch.randn(B, S, cfg.chunk_size, cfg.num_features, device=dev)
+eng.stage_path(0, 0, x)
+eng.set_option("lstm_stamps", 1)
+eng.stage_path(0, 0, x)
+torch.cuda.synchronize()
+raw = eng.tap("lstm_stamps", B, eng._path_T(S)).view(torch.int64).cpu().numpy()
+nst = (B * S + 31) // 32
+a = raw[: 2 * nst * 4 * 4].reshape(2, nst, 4, 4).astype(np.float64) / cfg.chunk_size
+print("cycles per step (mean over waves):  acc-init %.0f   mfma %.0f   cell %.0f   barrier %.0f   total %.0f"
+      % (*a.mean((0, 1, 2)), a.sum(-1).mean()))
+print("per wave (tile 0, dir 0):", a[0, 0].round(0).tolist())
+print("max-over-waves total:", a.sum(-1).max(), " min:", a.sum(-1).min())
