@@ -38,6 +38,28 @@ DEV float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408
 // 2/(1+e^-2x) - 1 : saturates correctly to +-1 (no inf/inf)
 DEV float fast_tanh(float x) { return fmaf(2.0f, fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * x)), -1.0f); }
 
+// Sum over groups of 16 or 32 adjacent lanes, result in every lane, entirely on the VALU (DPP + one
+// v_permlane16_swap): __shfl_xor lowers to ds_bpermute_b32, whose LDS-crossbar round trip (~100 cycles, waited
+// for with lgkmcnt(0)) dominated the LayerNorm epilogues.
+template <int CTRL>
+DEV float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int GROUP>
+DEV float group_sum(float v) {
+  static_assert(GROUP == 16 || GROUP == 32, "group size");
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]  -> quad sums
+  v += dpp_move<0x141>(v);   // row_half_mirror       -> 8-lane sums
+  v += dpp_move<0x140>(v);   // row_mirror            -> 16-lane sums
+  if (GROUP == 32) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows {0,1} and {2,3} exchange
+    v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+  return v;
+}
+
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to wave-uniform LDS base + lane*16 (no VGPR hop).
 DEV void glds16(const float* gsrc, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -117,16 +117,22 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
     {
+      // fragments are fetched in batches of 16 x ds_read_b128 BEFORE the MFMAs that use them: a read placed
+      // between MFMAs is followed by s_waitcnt lgkmcnt(0) and exposes a full LDS round trip per k-chunk
       const float* arow = &Ab[(wr * 32 + c) * Sh::LDA + 4 * hh];
+      constexpr int CH = KIN / 8, BATCH = CH < 16 ? CH : 16;
 #pragma unroll
-      for (int m = 0; m < KIN / 8; ++m) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + 8 * m);
+      for (int m0 = 0; m0 < CH; m0 += BATCH) {
+        float4 afr[BATCH];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[nt] = mfma32(a.x, wf[nt][4 * m + 0], acc[nt]);
-          acc[nt] = mfma32(a.y, wf[nt][4 * m + 1], acc[nt]);
-          acc[nt] = mfma32(a.z, wf[nt][4 * m + 2], acc[nt]);
-          acc[nt] = mfma32(a.w, wf[nt][4 * m + 3], acc[nt]);
+        for (int m = 0; m < BATCH; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 8 * (m0 + m));
+#pragma unroll
+        for (int m = 0; m < BATCH; ++m) {
+          const float av[4] = {afr[m].x, afr[m].y, afr[m].z, afr[m].w};
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[tt], wf[nt][4 * (m0 + m) + tt], acc[nt]);
         }
       }
     }
@@ -248,14 +254,10 @@ struct EpiBiasResLN {
     const bool ok = r < M;
     const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
     v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
-    float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+    const float s = group_sum<GROUP>((v.x + v.y) + (v.z + v.w));
     const float mu = s * (1.0f / (4 * GROUP));
     const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, GROUP);
+    const float q = group_sum<GROUP>((dx * dx + dy * dy) + (dz * dz + dw * dw));
     const float rstd = rsqrtf(q * (1.0f / (4 * GROUP)) + 1e-5f);
     if (!ok) return;
     const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);

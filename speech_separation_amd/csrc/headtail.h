@@ -76,9 +76,7 @@ __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restri
     const float4 bb = *reinterpret_cast<const float4*>(vid + ((int64_t)b * Tv + i1) * N + 4 * c4);
     float u[4] = {a.x * (1.f - lam) + bb.x * lam, a.y * (1.f - lam) + bb.y * lam, a.z * (1.f - lam) + bb.z * lam,
                   a.w * (1.f - lam) + bb.w * lam};
-    float s = (u[0] + u[1]) + (u[2] + u[3]);
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+    const float s = group_sum<GROUP>((u[0] + u[1]) + (u[2] + u[3]));
     const float mu = s * (1.0f / N);
     float q = 0.f;
 #pragma unroll
@@ -86,8 +84,7 @@ __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restri
       u[i] -= mu;
       q += u[i] * u[i];
     }
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, GROUP);
+    q = group_sum<GROUP>(q);
     const float rstd = rsqrtf(q * (1.0f / N) + 1e-5f);
     const float tg = tanhf(*gate);
     const float4 ga = *reinterpret_cast<const float4*>(ln_w + 4 * c4);
@@ -159,8 +156,7 @@ struct EpiSkipDecoderTaps {
     for (int j = 0; j < kenc; ++j) {
       float s = v.x * wdec[(4 * c4 + 0) * kenc + j] + v.y * wdec[(4 * c4 + 1) * kenc + j] +
                 v.z * wdec[(4 * c4 + 2) * kenc + j] + v.w * wdec[(4 * c4 + 3) * kenc + j];
-#pragma unroll
-      for (int o = GROUP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, GROUP);
+      s = group_sum<GROUP>(s);
       if (c4 == j) mine = s;
     }
     if (ok && c4 < 8) D[r * 8 + c4] = c4 < kenc ? mine : 0.f;
