@@ -15,7 +15,6 @@
 #include "gemm_ws.h"
 #include "headtail.h"
 #include "lstm.h"
-#include "lstm_pp.h"
 
 namespace {
 
@@ -341,7 +340,7 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
     if (int rc = launch_gemm<N, 1, WR, WC>(c, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, 1024, al, ep, st)) return rc;
   }
-  // K4: LSTM pre-activations for every (direction, sequence tile, position)
+  // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{y1, N, geom};
     EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};

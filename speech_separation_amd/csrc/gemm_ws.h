@@ -295,27 +295,3 @@ struct EpiLstmPre {
   }
 };
 
-// Same, in the PRE16 layout of lstm_pp.h: PRE16[d][st][t][sub][cb32][lane64][4]; accumulator registers 4q..4q+3 of
-// lane (c,hh) are rows 8q+4hh+i -> sub-tile q>>1, ks = 2(q&1)+hh; column c -> 16-column block 2cb+(c>>4), i16 = c&15.
-struct EpiLstmPre16 {
-  static constexpr bool DIRECT = true;
-  float* pre;
-  const float* b_ih[2];
-  const float* b_hh[2];
-  SeqGeom g;
-  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
-    const int st = tile / g.len, t = tile - st * g.len;
-    const int j = cb * 32 + c;
-    const float bias = b_ih[d][j] + b_hh[d][j];
-    float* base = pre + pre_tile_offset(d, st, t, g.nst, g.len) + (2 * cb + (c >> 4)) * 256 + (c & 15) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 v;
-      v.x = acc[4 * q + 0] + bias;
-      v.y = acc[4 * q + 1] + bias;
-      v.z = acc[4 * q + 2] + bias;
-      v.w = acc[4 * q + 3] + bias;
-      *reinterpret_cast<float4*>(base + (q >> 1) * 8192 + (2 * (q & 1) + hh) * 64) = v;
-    }
-  }
-};

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
           hc[oidx[slot - 16]] = hout[slot - 16];
           oidx[slot - 16] += adv;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (slot < 32) __builtin_amdgcn_sched_barrier(0);   // pin only the groups that carry side work
       }
     }
     if (STAMP) {
