@@ -52,6 +52,17 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def measured_traffic(tokens_per_launch: float):
+    """HBM bytes per LSTM launch from the committed PMC run (profiles/r01_lstm_hbm_traffic.json), rescaled to the
+    tokens one launch of THIS run covers; None if the file is absent.  bench.py cannot read PMC counters itself."""
+    path = os.path.join(ROOT, "profiles", "r01_lstm_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        return round(d["hbm_bytes_per_launch"] * tokens_per_launch / 169200.0)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def log(msg: str):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -135,16 +146,29 @@ def main():
     for _ in range(psteps):
         eng.forward(mix, e1, e2, out=out)
     prof = eng.profile_read()
+    # the dominant kernel once more with the two half-batches NOT overlapped (kernel alone on the chip)
+    eng.set_option("overlap", 0)
+    eng.profile_reset()
+    for _ in range(3):
+        eng.forward(mix, e1, e2, out=out)
+    prof_iso = eng.profile_read()
+    eng.set_option("overlap", 1)
     eng.profile(False)
     finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())
 
     if env.rank == 0:
         S, K, H = eng.chunks(T), cfg.chunk_size, cfg.hidden_dim
         M = B * S * K
+        # as run in the timed region: the batch is two overlapped halves, so one launch covers B/2 mixtures and shares
+        # the chip with the other half's GEMM / attention kernels
         ms, n = prof["lstm_recurrence"]
         lstm_ms = ms / max(n, 1)
-        lstm_flops = float(M) * 2 * (2 * H * 4 * H)            # per launch: both directions, h W_hh^T only
+        launches_per_step = n / psteps
+        lstm_flops = float(M) * 2 * (2 * H * 4 * H) * (2 * cfg.num_blocks) / launches_per_step   # per launch: both directions, h W_hh^T
         achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12
+        ms_i, n_i = prof_iso["lstm_recurrence"]
+        iso_ms = ms_i / max(n_i, 1)
+        iso_tflops = float(M) * 2 * (2 * H * 4 * H) / (iso_ms * 1e-3) / 1e12
         kernels = {k: round(v[0] / psteps, 4) for k, v in prof.items()}
         value = env.world * B * args.steps / elapsed
         line = {
@@ -158,7 +182,14 @@ def main():
                        "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": "lstm_recurrence_kernel", "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": None, "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
+                         "traffic": measured_traffic(M * 2 * cfg.num_blocks / launches_per_step),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_lstm_hbm_traffic.json)",
+                         "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (4 * 4 * H + 2 * H) * 4,
+                         "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
+                         "launches_per_step": launches_per_step,
+                         "isolated": {"note": "same kernel, whole batch in one launch, nothing else on the chip "
+                                              "(option overlap=0)", "launch_ms": round(iso_ms, 4),
+                                      "achieved": round(iso_tflops, 3), "frac": round(iso_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -123,6 +123,9 @@ int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* offset_bytes,
                          size_t* numel);
 /* Tuning / diagnostic knobs (never needed for correct results).  Keys:
+ *   "overlap" (0/1, default 1): dptnav_forward runs the batch as two halves on two internal streams (forked from
+ *                 and joined to the caller's stream by events) so that one half's GEMM/attention launches fill the
+ *                 CUs the other half's LSTM recurrence cannot use; 0 = everything on the caller's stream.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
  *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
 int dptnav_set_option(dptnav_handle h, const char* key, int value);

@@ -27,10 +27,27 @@ struct PathWeights {
   int ndir;
 };
 
+constexpr int QUEUE_SLOTS = 1024;
+
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, total;
   size_t qkv_n, att_n, y1_n, hc_n;
+};
+
+// One in-flight pass over a (sub-)batch: its workspace slice, stream and ticket-counter cursor.
+struct Run {
+  float* ws;
+  Plan pl;
+  hipStream_t st;
+  int slot;
+  hipEvent_t lstm_wait = nullptr;    // if set: the recurrence launch waits for this event (other half's recurrence)
+  hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
+  unsigned* take_queue(int n) {
+    unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
+    slot += n;
+    return q;
+  }
 };
 
 }  // namespace
@@ -50,6 +67,25 @@ struct dptnav_ctx {
   dptnav_config cfg;
   bool prof_on = false;
   bool opt_lstm_stamps = false;
+  bool opt_overlap = true;
+  hipStream_t streams[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
+  int ensure_streams() {
+    if (streams[0]) return 0;
+    for (int i = 0; i < 2; ++i) {
+      if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ev_lstm[i], hipEventDisableTiming) != hipSuccess) {
+        err = "cannot create internal streams/events";
+        return 4;
+      }
+    }
+    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) {
+      err = "cannot create fork event";
+      return 4;
+    }
+    return 0;
+  }
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_pool;
   double prof_ms[CAT_COUNT] = {0};
@@ -72,6 +108,7 @@ struct dptnav_ctx {
   int stride;
   int dh;
   int num_cus = 256;
+  std::vector<PathWeights> pw;   // [2*block + path], rebuilt by dptnav_bind_weights
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -219,6 +256,7 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
     o += align64(n);
     return at;
   };
+  p->queue = take(QUEUE_SLOTS);   // tile-ticket counters of the GEMM-engine launches (zeroed per call)
   p->vid = take((size_t)B * (Tv > 0 ? Tv : 1) * N);
   p->E = take((size_t)B * p->L * N);
   p->X0 = take((size_t)p->M * N);
@@ -291,8 +329,10 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 // The engine is persistent (grid-stride over tiles, weights loaded once per workgroup), so the grid is
 // sized to what is co-resident: CUs x blocks/CU from the occupancy query, queried once per instantiation.
 template <int KIN, int NT, int WR, int WC, class AL, class EP>
-int launch_gemm(dptnav_ctx* c, int cat, const char* what, const float* W, int64_t ntiles, int colgroups, int /*cap*/,
-                const AL& al, const EP& ep, hipStream_t st, const float* Walt = nullptr) {
+int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float* W, int64_t ntiles, int colgroups,
+                const AL& al, const EP& ep, const float* Walt = nullptr) {
+  hipStream_t st = run.st;
+  if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
   static int resident = 0;  // per instantiation
@@ -307,19 +347,21 @@ int launch_gemm(dptnav_ctx* c, int cat, const char* what, const float* W, int64_
   if (gx < 1) gx = 1;
   ProfScope ps(c, cat, st);
   hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
-                     al, ep);
+                     run.take_queue(colgroups), al, ep);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
 
 // ---- one TransformerDPRNN (dptn.py:36-52) ---------------------------------------------------------
 template <int N>
-int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out, int B, int S, float* ws,
-             const Plan& pl, hipStream_t st) {
+int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S) {
+  float* ws = run.ws;
+  const Plan& pl = run.pl;
+  hipStream_t st = run.st;
   constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4, DH = N / 4;
   constexpr int BM = 32 * WR;
   const dptnav_config& g = c->cfg;
-  const PathWeights w = path_weights(c, block, path);
+  const PathWeights& w = c->pw[2 * block + path];
   const int K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K;
   const SeqGeom geom = make_geom(path, B, S, K);
@@ -330,7 +372,7 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
   {
     ALoadDense al{x_in, M, N, BM};
     EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
-    if (int rc = launch_gemm<N, 3, WR, WC>(c, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, 512, al, ep, st)) return rc;
+    if (int rc = launch_gemm<N, 3, WR, WC>(c, run, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, al, ep)) return rc;
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
@@ -338,14 +380,14 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
   {
     ALoadDense al{att, M, N, BM};
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
-    if (int rc = launch_gemm<N, 1, WR, WC>(c, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, 1024, al, ep, st)) return rc;
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
   }
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{y1, N, geom};
     EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
-    if (int rc = launch_gemm<N, 4, 1, 4>(c, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, 512, al, ep, st, w.w_ih[1]))
+    if (int rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]))
       return rc;
   }
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
@@ -354,28 +396,35 @@ int run_path(dptnav_ctx* c, int block, int path, const float* x_in, float* x_out
     if (int rc = set_lds(c, kern, LSTM_LDS_BYTES, "lstm")) return rc;
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
+    if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
+      return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
                        w.ndir * LSTM_H, (int)M, geom, stamps);
     LAUNCH_CHECK(c, "lstm");
   }
+  if (run.lstm_record && hipEventRecord(run.lstm_record, st) != hipSuccess)
+    return c->fail(DPTNAV_ERR_HIP, "lstm stagger record");
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
   {
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
     if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
-      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else {
       ALoadDense al{hc, M, LSTM_H, BM};
-      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, 1024, al, ep, st)) return rc;
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     }
   }
   return DPTNAV_OK;
 }
 
 template <int N>
-int run_head(dptnav_ctx* c, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
-             float* E, float* X, float* ws, const Plan& pl, hipStream_t st) {
+int run_head(dptnav_ctx* c, Run& run, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+             float* E, float* X) {
+  float* ws = run.ws;
+  const Plan& pl = run.pl;
+  hipStream_t st = run.st;
   const dptnav_config& g = c->cfg;
   const float* vid = nullptr;
   if (!g.audio_only) {
@@ -397,8 +446,10 @@ int run_head(dptnav_ctx* c, const float* mix, const float* e1, const float* e2, 
 }
 
 template <int N>
-int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, float* s1, float* s2, float* ws,
-             const Plan& pl, hipStream_t st) {
+int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int64_t T, float* s1, float* s2) {
+  float* ws = run.ws;
+  const Plan& pl = run.pl;
+  hipStream_t st = run.st;
   constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4;
   constexpr int BM = 32 * WR;
   const dptnav_config& g = c->cfg;
@@ -408,8 +459,8 @@ int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, fl
   {
     ALoadDensePReLU al{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
     EpiBiasStore ep{Z, c->w("dprnn.speakers_separation.1.bias"), M, 2 * N, 32, 2 * N};
-    if (int rc = launch_gemm<N, N / 64, 1, 4>(c, CAT_SEP, "separation gemm", c->w("dprnn.speakers_separation.1.weight"),
-                                              (M + 31) / 32, 1, 1024, al, ep, st))
+    if (int rc = launch_gemm<N, N / 64, 1, 4>(c, run, CAT_SEP, "separation gemm",
+                                              c->w("dprnn.speakers_separation.1.weight"), (M + 31) / 32, 1, al, ep))
       return rc;
   }
   // T2: overlap-add gather -> post-processing conv -> + E -> decoder tap products
@@ -420,8 +471,8 @@ int run_tail(dptnav_ctx* c, const float* x, const float* E, int B, int64_t T, fl
     ALoadOla al{Z, N, B, (int)pl.L, (int)pl.S, g.chunk_size, g.step_size, left, ola, BM};
     EpiSkipDecoderTaps<GROUP> ep{D, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"),
                                  (int64_t)B * pl.L, g.kernel_size_enc, BM};
-    if (int rc = launch_gemm<N, 1, WR, WC>(c, CAT_POST, "postproc gemm", c->w("dprnn.postprocessing.0.weight"),
-                                           (rows + BM - 1) / BM, 1, 1024, al, ep, st))
+    if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_POST, "postproc gemm", c->w("dprnn.postprocessing.0.weight"),
+                                           (rows + BM - 1) / BM, 1, al, ep))
       return rc;
   }
   // T3: transposed-conv gather + zero padding
@@ -443,6 +494,17 @@ int check_common(dptnav_ctx* c, int B, int64_t T, int Tv, void* ws, size_t ws_by
     return c->fail(DPTNAV_ERR_WORKSPACE, "workspace must be non-null and 256-byte aligned");
   if (ws_bytes < pl->total * sizeof(float))
     return c->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, pl->total * sizeof(float));
+  return DPTNAV_OK;
+}
+
+// Start a pass on `st` over the workspace slice `ws`: zero its ticket counters (stream ordered).
+int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st) {
+  run->ws = ws;
+  run->pl = pl;
+  run->st = st;
+  run->slot = 0;
+  hipError_t e = hipMemsetAsync(ws + pl.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st);
+  if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "ticket counter reset: %s", hipGetErrorString(e));
   return DPTNAV_OK;
 }
 
@@ -497,6 +559,12 @@ void dptnav_destroy(dptnav_handle h) {
   if (!h) return;
   for (ProfRec& r : h->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (h->streams[i]) hipStreamDestroy(h->streams[i]);
+    if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
+    if (h->ev_lstm[i]) hipEventDestroy(h->ev_lstm[i]);
+  }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   delete h;
 }
 
@@ -518,6 +586,9 @@ int dptnav_bind_weights(dptnav_handle h, const float* const* dev_ptrs, int n) {
       return h->fail(DPTNAV_ERR_WEIGHTS, "%s is not 16-byte aligned", h->names[i].c_str());
   }
   h->ptr.assign(dev_ptrs, dev_ptrs + n);
+  h->pw.clear();
+  for (int b = 0; b < h->cfg.num_blocks; ++b)
+    for (int p = 0; p < 2; ++p) h->pw.push_back(path_weights(h, b, p));
   h->bound = true;
   return DPTNAV_OK;
 }
@@ -533,7 +604,14 @@ size_t dptnav_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
   if (!h) return 0;
   Plan pl;
   if (make_plan(h, B, T, Tv, &pl)) return 0;
-  return pl.total * sizeof(float);
+  size_t need = pl.total;
+  if (B >= 2) {   // dptnav_forward splits the batch into two independently planned halves
+    Plan a, b;
+    if (make_plan(h, (B + 1) / 2, T, Tv, &a) || make_plan(h, B / 2, T, Tv, &b)) return 0;
+    const size_t two = ((a.total + 63) & ~(size_t)63) + ((b.total + 63) & ~(size_t)63);
+    if (two > need) need = two;
+  }
+  return need * sizeof(float);
 }
 
 int dptnav_stage_head(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
@@ -543,9 +621,10 @@ int dptnav_stage_head(dptnav_handle h, const float* mix, const float* e1, const 
   if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
   if (!mix || !encoded || !chunked || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1)))
     return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
-  hipStream_t st = (hipStream_t)stream;
-  return h->cfg.num_features == 128 ? run_head<128>(h, mix, e1, e2, B, T, Tv, encoded, chunked, (float*)ws, pl, st)
-                                    : run_head<64>(h, mix, e1, e2, B, T, Tv, encoded, chunked, (float*)ws, pl, st);
+  Run run;
+  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  return h->cfg.num_features == 128 ? run_head<128>(h, run, mix, e1, e2, B, T, Tv, encoded, chunked)
+                                    : run_head<64>(h, run, mix, e1, e2, B, T, Tv, encoded, chunked);
 }
 
 int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S, void* ws,
@@ -560,9 +639,10 @@ int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, f
   const int64_t T = (L - 1) * h->stride + h->cfg.kernel_size_enc;
   Plan pl;
   if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  return h->cfg.num_features == 128 ? run_path<128>(h, block, path, x_in, x_out, B, S, (float*)ws, pl, st)
-                                    : run_path<64>(h, block, path, x_in, x_out, B, S, (float*)ws, pl, st);
+  Run run;
+  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  return h->cfg.num_features == 128 ? run_path<128>(h, run, block, path, x_in, x_out, B, S)
+                                    : run_path<64>(h, run, block, path, x_in, x_out, B, S);
 }
 
 int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int B, int64_t T, float* s1, float* s2,
@@ -571,34 +651,94 @@ int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int
   Plan pl;
   if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
   if (!x || !encoded || !s1 || !s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
-  hipStream_t st = (hipStream_t)stream;
-  return h->cfg.num_features == 128 ? run_tail<128>(h, x, encoded, B, T, s1, s2, (float*)ws, pl, st)
-                                    : run_tail<64>(h, x, encoded, B, T, s1, s2, (float*)ws, pl, st);
+  Run run;
+  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  return h->cfg.num_features == 128 ? run_tail<128>(h, run, x, encoded, B, T, s1, s2)
+                                    : run_tail<64>(h, run, x, encoded, B, T, s1, s2);
 }
 
 int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
                    float* s1, float* s2, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  Plan pl;
-  if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
+  if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "weights not bound: call dptnav_bind_weights first");
   if (!mix || !s1 || !s2 || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1)))
     return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  if (ws == nullptr || ((uintptr_t)ws & 255) != 0)
+    return h->fail(DPTNAV_ERR_WORKSPACE, "workspace must be non-null and 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  float* w = (float*)ws;
-  float *E = w + pl.E, *X0 = w + pl.X0, *X1 = w + pl.X1;
   const bool big = h->cfg.num_features == 128;
-  int rc = big ? run_head<128>(h, mix, e1, e2, B, T, Tv, E, X0, w, pl, st)
-               : run_head<64>(h, mix, e1, e2, B, T, Tv, E, X0, w, pl, st);
-  if (rc) return rc;
-  for (int b = 0; b < h->cfg.num_blocks; ++b) {
-    rc = big ? run_path<128>(h, b, 0, X0, X1, B, (int)pl.S, w, pl, st)
-             : run_path<64>(h, b, 0, X0, X1, B, (int)pl.S, w, pl, st);
-    if (rc) return rc;
-    rc = big ? run_path<128>(h, b, 1, X1, X0, B, (int)pl.S, w, pl, st)
-             : run_path<64>(h, b, 1, X1, X0, B, (int)pl.S, w, pl, st);
+  const dptnav_config& g = h->cfg;
+
+  // Mixtures are independent, so the batch is processed as two halves on two internal streams: the LSTM
+  // recurrence can only occupy 2 x ceil(sequences/32) CUs, and the other half's GEMM / attention launches
+  // (dynamic tile tickets) fill the rest of the chip meanwhile.  Fork/join by events on the caller's stream.
+  const int nhalf = (h->opt_overlap && B >= 2) ? 2 : 1;
+  int Bh[2] = {nhalf == 2 ? (B + 1) / 2 : B, nhalf == 2 ? B / 2 : 0};
+  Plan pl[2];
+  size_t need = 0, base[2] = {0, 0};
+  for (int i = 0; i < nhalf; ++i) {
+    if (int rc = make_plan(h, Bh[i], T, Tv, &pl[i])) return rc;
+    base[i] = need;
+    need += (pl[i].total + 63) & ~(size_t)63;
+  }
+  if (ws_bytes < need * sizeof(float))
+    return h->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need * sizeof(float));
+  if (nhalf == 2) {
+    if (int rc = h->ensure_streams()) return rc;
+    if (hipEventRecord(h->ev_fork, st) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork event");
+  }
+  const int64_t Cv = g.audio_only ? 0 : g.video_emb_size;
+  Run run[2];
+  const float *mixi[2], *e1i[2], *e2i[2];
+  float *s1i[2], *s2i[2];
+  for (int i = 0; i < nhalf; ++i) {
+    hipStream_t si = nhalf == 2 ? h->streams[i] : st;
+    if (nhalf == 2 && hipStreamWaitEvent(si, h->ev_fork, 0) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork wait");
+    const int64_t b0 = i == 0 ? 0 : Bh[0];
+    if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
+    mixi[i] = mix + b0 * T;
+    e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
+    e2i[i] = e2 ? e2 + b0 * Cv * Tv : nullptr;
+    s1i[i] = s1 + b0 * T;
+    s2i[i] = s2 + b0 * T;
+  }
+  // The halves advance in lock step on the host, but their recurrences are chained by events
+  // (L(h0,p) -> L(h1,p) -> L(h0,p+1) ...): at any time at most ONE half sits in the LSTM (<= 76 CUs) while the
+  // other half's GEMM / attention kernels use the remaining CUs -- without the chain both halves reach the
+  // recurrence together and nothing is gained.
+  auto E = [&](int i) { return run[i].ws + run[i].pl.E; };
+  auto X0 = [&](int i) { return run[i].ws + run[i].pl.X0; };
+  auto X1 = [&](int i) { return run[i].ws + run[i].pl.X1; };
+  for (int i = 0; i < nhalf; ++i) {
+    int rc = big ? run_head<128>(h, run[i], mixi[i], e1i[i], e2i[i], Bh[i], T, Tv, E(i), X0(i))
+                 : run_head<64>(h, run[i], mixi[i], e1i[i], e2i[i], Bh[i], T, Tv, E(i), X0(i));
     if (rc) return rc;
   }
-  return big ? run_tail<128>(h, X0, E, B, T, s1, s2, w, pl, st) : run_tail<64>(h, X0, E, B, T, s1, s2, w, pl, st);
+  bool have_prev = false;
+  for (int b = 0; b < g.num_blocks; ++b)
+    for (int path = 0; path < 2; ++path)
+      for (int i = 0; i < nhalf; ++i) {
+        if (nhalf == 2) {
+          run[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
+          run[i].lstm_record = h->ev_lstm[i];
+        }
+        const float* xin = path == 0 ? X0(i) : X1(i);
+        float* xout = path == 0 ? X1(i) : X0(i);
+        int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bh[i], (int)pl[i].S)
+                     : run_path<64>(h, run[i], b, path, xin, xout, Bh[i], (int)pl[i].S);
+        if (rc) return rc;
+        have_prev = true;
+      }
+  for (int i = 0; i < nhalf; ++i) {
+    int rc = big ? run_tail<128>(h, run[i], X0(i), E(i), Bh[i], T, s1i[i], s2i[i])
+                 : run_tail<64>(h, run[i], X0(i), E(i), Bh[i], T, s1i[i], s2i[i]);
+    if (rc) return rc;
+    if (nhalf == 2) {
+      if (hipEventRecord(h->ev_join[i], run[i].st) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess)
+        return h->fail(DPTNAV_ERR_HIP, "join event");
+    }
+  }
+  return DPTNAV_OK;
 }
 
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* off, size_t* numel) {
@@ -621,6 +761,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   if (!h || !key) return DPTNAV_ERR_INVALID;
   const std::string k(key);
   if (k == "lstm_stamps") h->opt_lstm_stamps = value != 0;
+  else if (k == "overlap") h->opt_overlap = value != 0;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }

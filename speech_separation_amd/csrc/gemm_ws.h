@@ -27,19 +27,20 @@ struct GemmShape {
   static constexpr int LDC = WGCOLS + 4;
   static constexpr int KS = KIN / 2;       // MFMA k-steps
   static constexpr size_t lds_bytes(bool direct) {
-    return sizeof(float) * (2 * (size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
+    return sizeof(float) * (4 + 2 * (size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
   }
 };
 
 template <int KIN, int NT, int WR, int WC, class ALoad, class Epi>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ W,
                                                        const float* __restrict__ Walt, int ldw, int ntiles,
-                                                       ALoad aload, Epi epi) {
+                                                       unsigned* __restrict__ tile_queue, ALoad aload, Epi epi) {
   using Sh = GemmShape<KIN, NT, WR, WC>;
   static_assert(WR * WC == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;
-  float* Cs = smem + 2 * Sh::BM * Sh::LDA;
+  int* s_next = reinterpret_cast<int*>(smem);       // [2] tile tickets (double buffered), 16-byte slot
+  float* As = smem + 4;
+  float* Cs = As + 2 * Sh::BM * Sh::LDA;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
@@ -75,8 +76,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   // Software pipeline: the A tile of iteration i+1 is fetched into registers while iteration i computes;
   // As is double buffered, so one barrier orders "tile written" -> "fragments read" and nothing else is needed
   // for As (a buffer is rewritten two iterations later, behind the next iteration's barrier).
+  // Tiles are handed out by a device-wide ticket counter (one per column group, zeroed by the host before the
+  // launch) instead of a static grid-stride: when this kernel shares the chip with another stream's kernel
+  // (dptnav_forward overlaps two half-batches), workgroups that start late simply find fewer tickets left.
+  unsigned* queue = tile_queue + colgroup;
+  if (tid == 0) s_next[0] = (int)atomicAdd(queue, 1u);
+  __syncthreads();
   float4 pf[NLD];
-  int tile = blockIdx.x;
+  int tile = s_next[0];
   if (tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -85,8 +92,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     }
   }
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+  while (tile < ntiles) {
     float* Ab = As + buf * (Sh::BM * Sh::LDA);
+    if (tid == 0) s_next[buf ^ 1] = (int)atomicAdd(queue, 1u);   // ticket of the next iteration
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     }
     __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
 
-    const int next = tile + gridDim.x;
+    const int next = s_next[buf ^ 1];
     if (next < ntiles) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
@@ -157,6 +165,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         epi.row(tile, row, colgroup, c4, v, epf[p]);
       }
     }
+    tile = next;
+    buf ^= 1;
   }
 }
 
