@@ -184,7 +184,7 @@ def main():
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": measured_traffic(M * 2 * cfg.num_blocks / launches_per_step),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_lstm_hbm_traffic.json)",
-                         "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (4 * 4 * H + 2 * H) * 4,
+                         "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (8 * H + 2 * H) * 4,
                          "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
                          "launches_per_step": launches_per_step,
                          "isolated": {"note": "same kernel, whole batch in one launch, nothing else on the chip "
