@@ -169,6 +169,31 @@ def dptn_block(x: np.ndarray, p: Dict[str, np.ndarray], b: int, heads: int,
     return out
 
 
+def dprnn_path(x: np.ndarray, p: Dict[str, np.ndarray], pre: str) -> np.ndarray:
+    """IntraChunkRNN / InterChunkRNN on sequence-major input (dprnn.py:24-47, 65-89): (bi)LSTM -> Linear ->
+    LayerNorm over the features -> + residual.  NB the norm comes BEFORE the residual add and there is no ReLU."""
+    hs = [lstm_direction(x, p[pre + "rnn.weight_ih_l0"], p[pre + "rnn.weight_hh_l0"],
+                         p[pre + "rnn.bias_ih_l0"], p[pre + "rnn.bias_hh_l0"], False)]
+    if pre + "rnn.weight_ih_l0_reverse" in p:
+        hs.append(lstm_direction(x, p[pre + "rnn.weight_ih_l0_reverse"], p[pre + "rnn.weight_hh_l0_reverse"],
+                                 p[pre + "rnn.bias_ih_l0_reverse"], p[pre + "rnn.bias_hh_l0_reverse"], True))
+    y = np.concatenate(hs, -1) @ p[pre + "fc.weight"].T + p[pre + "fc.bias"]
+    return layer_norm(y, p[pre + "norm1d.weight"], p[pre + "norm1d.bias"]) + x
+
+
+def dprnn_block(x: np.ndarray, p: Dict[str, np.ndarray], b: int, taps: Optional[dict] = None) -> np.ndarray:
+    """DPRNNBlock.forward (dprnn.py:103-113).  x (B,N,S,K) -> (B,N,S,K); taps are in that layout too."""
+    B, N, S, K = x.shape
+    pre = f"dprnn.model.{b}."
+    intra = dprnn_path(x.transpose(0, 2, 3, 1).reshape(B * S, K, N), p, pre + "intra_chunk_block.")
+    intra = intra.reshape(B, S, K, N).transpose(0, 3, 1, 2)                                 # b n s k
+    inter = dprnn_path(intra.transpose(0, 3, 2, 1).reshape(B * K, S, N), p, pre + "inter_chunk_block.")
+    out = inter.reshape(B, K, S, N).transpose(0, 3, 2, 1)                                   # b n s k
+    if taps is not None:
+        taps[f"blk{b}_intra"], taps[f"blk{b}_inter"], taps[f"blk{b}_out"] = intra, out, out
+    return out
+
+
 def separation_tail(x: np.ndarray, L: int, p: Dict[str, np.ndarray], P: int,
                     taps: Optional[dict] = None) -> np.ndarray:
     """A8: DPTNWav.forward tail (dptn_wav.py:47-61).  PReLU (one slope) -> Conv2d 1x1 (N->2N) ->
@@ -215,7 +240,10 @@ def decoder_deconv(x: np.ndarray, w: np.ndarray, stride: int, T: int) -> np.ndar
 def forward(cfg, params: Dict[str, np.ndarray], mix: np.ndarray, s1_embedding: Optional[np.ndarray] = None,
             s2_embedding: Optional[np.ndarray] = None, dtype=np.float32, taps: Optional[dict] = None,
             **_ignored) -> Dict[str, np.ndarray]:
-    """DPTNAVWavEncDec.forward (dptn_wav.py:171-194) / DPTNWavEncDec.forward (:105-117).
+    """DPTNAVWavEncDec.forward (dptn_wav.py:171-194) / DPTNWavEncDec.forward (:105-117) / DPRNNEncDec.forward
+    (dprnn.py:260-274; arch == "dprnn").  The head and the tail are the same code in all three (DPRNN.forward
+    dprnn.py:200-227 == DPTNWav.forward dptn_wav.py:35-61).  arch == "dprnn" with audio_only == False is this
+    repo's "DPRNN-AV" (BASELINE config 5): the reference has no such class, so only its parts are pinned.
     Extra batch keys are swallowed like the reference's **batch."""
     p = {k: np.asarray(v, dtype=dtype) for k, v in params.items()}
     mix = np.asarray(mix, dtype=dtype)
@@ -230,7 +258,7 @@ def forward(cfg, params: Dict[str, np.ndarray], mix: np.ndarray, s1_embedding: O
     if taps is not None:
         taps["encoded"], taps["chunked"] = enc, x
     for b in range(cfg.num_blocks):
-        x = dptn_block(x, p, b, cfg.num_heads, taps)
+        x = dptn_block(x, p, b, cfg.num_heads, taps) if cfg.arch == "dptn" else dprnn_block(x, p, b, taps)
     masks = separation_tail(x, L, p, cfg.step_size, taps)
     preds = [decoder_deconv(masks[j] + enc, p["decoder.weight"], cfg.stride_enc, T) for j in range(2)]
     return {"s1_pred": preds[0], "s2_pred": preds[1]}

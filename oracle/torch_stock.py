@@ -32,14 +32,20 @@ class StockDPTN:
             for name in ("intra_chunk_block", "inter_chunk_block"):
                 pre = f"dprnn.model.{b}.{name}."
                 two = name == "intra_chunk_block" or cfg.bidir
-                mha = nn.MultiheadAttention(N, cfg.num_heads, dropout=cfg.dropout, batch_first=True)
                 rnn = nn.LSTM(N, H, bidirectional=two, batch_first=True)
-                mha.load_state_dict({k[len(pre) + 4:]: v for k, v in sd.items() if k.startswith(pre + "mha.")})
                 rnn.load_state_dict({k[len(pre) + 4:]: v for k, v in sd.items() if k.startswith(pre + "rnn.")})
-                self.paths.append((pre, mha.eval(), rnn.eval()))
+                mha = None
+                if cfg.arch == "dptn":
+                    mha = nn.MultiheadAttention(N, cfg.num_heads, dropout=cfg.dropout, batch_first=True)
+                    mha.load_state_dict({k[len(pre) + 4:]: v for k, v in sd.items() if k.startswith(pre + "mha.")})
+                    mha.eval()
+                self.paths.append((pre, mha, rnn.eval()))
 
     def _path(self, x, pre, mha, rnn):
         sd, N = self.sd, self.cfg.num_features
+        if mha is None:   # DPRNN: dprnn.py:24-47,65-89
+            y = F.linear(rnn(x)[0], sd[pre + "fc.weight"], sd[pre + "fc.bias"])
+            return F.layer_norm(y, (N,), sd[pre + "norm1d.weight"], sd[pre + "norm1d.bias"]) + x
         y = mha(x, x, x, need_weights=False)[0] + x
         y = F.layer_norm(y, (N,), sd[pre + "ln1.weight"], sd[pre + "ln1.bias"])
         r = rnn(y)[0]

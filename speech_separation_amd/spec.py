@@ -38,7 +38,8 @@ class DPTNConfig:
     num_heads: int = 4
     dropout: float = 0.1
     bidir: bool = True
-    audio_only: bool = False  # True -> DPTNWavEncDec (no video branch)
+    audio_only: bool = False  # True -> DPTNWavEncDec / DPRNNEncDec (no video branch)
+    arch: str = "dptn"        # "dptn": MHA + bi-LSTM blocks (dptn.py); "dprnn": bi-LSTM + fc blocks (dprnn.py:7-113)
 
     # ---- derived sizes -------------------------------------------------
     @property
@@ -71,10 +72,30 @@ class DPTNConfig:
 DPTN_AV = DPTNConfig()
 #: BASELINE.json config 2 (src/configs/model/dptn_wav.yaml)
 DPTN_AUDIO = DPTNConfig(num_features=64, audio_only=True)
+#: BASELINE.json config 5 backbone (src/configs/model/dprnn.yaml): audio-only DPRNNEncDec is the only variant the
+#: reference defines; audio_only=False adds this repo's AV fusion head (same as dptn_wav.py:173-184) = "DPRNN-AV"
+DPRNN_AUDIO = DPTNConfig(num_features=64, hidden_video=64, kernel_size_enc=2, hidden_dim=128, num_blocks=6,
+                         chunk_size=250, step_size=125, audio_only=True, arch="dprnn")
+DPRNN_AV = DPTNConfig(**{**DPRNN_AUDIO.__dict__, "audio_only": False})
 #: small shape used by the golden fixtures (fast on every backend)
 DPTN_TINY = DPTNConfig(num_features=32, video_emb_size=24, hidden_video=32, kernel_size_enc=7,
                        hidden_dim=32, num_blocks=2, chunk_size=10, step_size=5, num_heads=4)
 
+
+_DPRNN_PATH_TENSORS: List[Tuple[str, str]] = [
+    ("rnn.weight_ih_l0", "4H,N"),
+    ("rnn.weight_hh_l0", "4H,H"),
+    ("rnn.bias_ih_l0", "4H"),
+    ("rnn.bias_hh_l0", "4H"),
+    ("rnn.weight_ih_l0_reverse", "4H,N"),
+    ("rnn.weight_hh_l0_reverse", "4H,H"),
+    ("rnn.bias_ih_l0_reverse", "4H"),
+    ("rnn.bias_hh_l0_reverse", "4H"),
+    ("fc.weight", "N,DH"),
+    ("fc.bias", "N"),
+    ("norm1d.weight", "N"),
+    ("norm1d.bias", "N"),
+]
 
 _PATH_TENSORS: List[Tuple[str, str]] = [
     # (suffix, shape-code)
@@ -118,7 +139,7 @@ def state_dict_spec(cfg: DPTNConfig) -> List[Tuple[str, Tuple[int, ...]]]:
         for path in ("intra_chunk_block", "inter_chunk_block"):
             two_dirs = True if path == "intra_chunk_block" else cfg.bidir
             dims = {"N": N, "3N": 3 * N, "4H": 4 * H, "H": H, "DH": H * (2 if two_dirs else 1)}
-            for suffix, code in _PATH_TENSORS:
+            for suffix, code in (_PATH_TENSORS if cfg.arch == "dptn" else _DPRNN_PATH_TENSORS):
                 if suffix.endswith("_reverse") and not two_dirs:
                     continue
                 shape = tuple(dims[c] for c in code.split(","))
@@ -153,9 +174,9 @@ def synthetic_state_dict(cfg: DPTNConfig, seed: int = 0) -> Dict[str, np.ndarray
             w = np.array([0.7], dtype=np.float64)
         elif key == "dprnn.speakers_separation.0.weight":
             w = np.array([0.25], dtype=np.float64)
-        elif ("ln" in key.split(".")[-2]) and leaf == "weight":
+        elif (key.split(".")[-2].startswith(("ln", "video_ln", "norm1d"))) and leaf == "weight":
             w = 1.0 + 0.1 * rng.standard_normal(shape)
-        elif ("ln" in key.split(".")[-2]) and leaf == "bias":
+        elif (key.split(".")[-2].startswith(("ln", "video_ln", "norm1d"))) and leaf == "bias":
             w = 0.05 * rng.standard_normal(shape)
         else:
             if leaf.startswith("bias") or leaf.endswith("bias"):

@@ -18,7 +18,7 @@ def _split(z):
     return w, i, t
 
 
-@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_unidir"])
+@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_unidir", "tiny_dprnn", "tiny_dprnn_unidir"])
 def test_every_stage_matches_reference(golden, name):
     cfg, z = golden(name)
     w, inp, ref = _split(z)
@@ -60,7 +60,7 @@ def test_metric_consistent_with_reference_loss(golden):
             assert abs(db - (-float(z[f"val.sisnr_loss_{a}_{b}"]) / 2)) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["mid_av", "mid_audio"])
+@pytest.mark.parametrize("name", ["mid_av", "mid_audio", "mid_dprnn"])
 def test_real_feature_sizes_match_reference(golden, name):
     cfg, z = golden(name)
     B, T, Tv = (int(v) for v in z["shape"])
@@ -80,7 +80,7 @@ def test_real_feature_sizes_match_reference(golden, name):
     assert d < 1e-3
 
 
-@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_unidir"])
+@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_unidir", "tiny_dprnn", "tiny_dprnn_unidir"])
 def test_stock_torch_composition_matches_reference(golden, name):
     """oracle/torch_stock.py (the cpu_baseline 'port') reproduces the reference outputs."""
     import torch

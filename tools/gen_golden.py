@@ -26,7 +26,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from speech_separation_amd.spec import (DPTN_AV, DPTN_AUDIO, DPTN_TINY, DPTNConfig,  # noqa: E402
+from speech_separation_amd.spec import (DPRNN_AUDIO, DPTN_AV, DPTN_AUDIO, DPTN_TINY, DPTNConfig,  # noqa: E402
                                         state_dict_spec, synthetic_inputs, synthetic_state_dict)
 
 REF = "/root/reference"
@@ -40,6 +40,7 @@ def import_reference():
         sys.modules[name] = m
     sys.path.insert(0, REF)
     dptn_wav = importlib.import_module("src.model.dptn_wav")
+    dptn_wav.DPRNNEncDec = importlib.import_module("src.model.dprnn").DPRNNEncDec
     losses = importlib.import_module("src.loss.ss_losses")
     return dptn_wav, losses
 
@@ -56,7 +57,11 @@ def build_reference(dptn_wav, cfg: DPTNConfig, sd):
     kw = dict(num_features=cfg.num_features, kernel_size_enc=cfg.kernel_size_enc, hidden_dim=cfg.hidden_dim,
               num_blocks=cfg.num_blocks, chunk_size=cfg.chunk_size, step_size=cfg.step_size,
               num_heads=cfg.num_heads, dropout=cfg.dropout, bidir=cfg.bidir)
-    if cfg.audio_only:
+    if cfg.arch == "dprnn":
+        assert cfg.audio_only, "the reference only defines the audio-only DPRNNEncDec"
+        kw.pop("num_heads"), kw.pop("dropout")
+        model = dptn_wav.DPRNNEncDec(**kw)
+    elif cfg.audio_only:
         model = dptn_wav.DPTNWavEncDec(**kw)
     else:
         model = dptn_wav.DPTNAVWavEncDec(video_emb_size=cfg.video_emb_size, hidden_video=cfg.hidden_video, **kw)
@@ -125,7 +130,11 @@ def main():
 
     # ---- 1. tiny config: every stage tensor, weights and inputs stored ----
     for name, cfg in (("tiny_av", DPTN_TINY), ("tiny_audio", DPTNConfig(**{**DPTN_TINY.to_dict(), "audio_only": True})),
-                      ("tiny_unidir", DPTNConfig(**{**DPTN_TINY.to_dict(), "bidir": False}))):
+                      ("tiny_unidir", DPTNConfig(**{**DPTN_TINY.to_dict(), "bidir": False})),
+                      ("tiny_dprnn", DPTNConfig(**{**DPTN_TINY.to_dict(), "audio_only": True, "arch": "dprnn",
+                                                   "kernel_size_enc": 2})),
+                      ("tiny_dprnn_unidir", DPTNConfig(**{**DPTN_TINY.to_dict(), "audio_only": True, "arch": "dprnn",
+                                                          "bidir": False}))):
         sd = synthetic_state_dict(cfg, seed=7)
         inp = synthetic_inputs(cfg, B=2, T=209, Tv=9, seed=11)
         model = build_reference(dptn_wav, cfg, sd)
@@ -142,6 +151,7 @@ def main():
         ("mid_av", DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2}), dict(B=2, T=8000, Tv=50)),
         ("mid_audio", DPTNConfig(**{**DPTN_AUDIO.to_dict(), "num_blocks": 2}), dict(B=2, T=8000, Tv=50)),
         ("full_av", DPTN_AV, dict(B=1, T=32000, Tv=50)),
+        ("mid_dprnn", DPTNConfig(**{**DPRNN_AUDIO.to_dict(), "num_blocks": 2}), dict(B=2, T=3000, Tv=50)),
     ]
     for name, cfg, shp in cases:
         sd = synthetic_state_dict(cfg, seed=0)
