@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPTNAV_ABI_VERSION 1
+#define DPTNAV_ABI_VERSION 2
 
 /* error codes */
 #define DPTNAV_OK 0
@@ -59,7 +59,10 @@ typedef struct dptnav_config {
   int32_t step_size;       /* P = 75                                                            */
   int32_t num_heads;       /* 4; head dim N/heads must be 32 or 16                              */
   int32_t bidir;           /* inter-chunk LSTM bidirectional (intra always is, dptn.py:59)      */
-  int32_t audio_only;      /* 1 -> DPTNWavEncDec (no video branch, no gate)                     */
+  int32_t audio_only;      /* 1 -> DPTNWavEncDec / DPRNNEncDec (no video branch, no gate)       */
+  int32_t arch;            /* 0: DPTN blocks = TransformerDPRNN (dptn.py:9-52)
+                              1: DPRNN blocks = IntraChunkRNN/InterChunkRNN (dprnn.py:7-89): LSTM -> fc -> LayerNorm -> +res,
+                                 no attention; head and tail are identical (dprnn.py:200-227,260-274)           */
 } dptnav_config;
 
 typedef struct dptnav_ctx* dptnav_handle;

@@ -1,7 +1,7 @@
 """speech_separation_amd -- MI355X-native DPTN(-AV) separation forward path (libdptnav + thin host layer)."""
-from .spec import DPTN_AUDIO, DPTN_AV, DPTNConfig, state_dict_spec, synthetic_inputs, synthetic_state_dict
+from .spec import DPRNN_AUDIO, DPRNN_AV, DPTN_AUDIO, DPTN_AV, DPTNConfig, state_dict_spec, synthetic_inputs, synthetic_state_dict
 
-__all__ = ["DPTNConfig", "DPTN_AV", "DPTN_AUDIO", "state_dict_spec", "synthetic_state_dict", "synthetic_inputs",
+__all__ = ["DPTNConfig", "DPTN_AV", "DPTN_AUDIO", "DPRNN_AUDIO", "DPRNN_AV", "DPRNNEncDec", "DPRNNAVEncDec", "state_dict_spec", "synthetic_state_dict", "synthetic_inputs",
            "DptnEngine", "DPTNAVWavEncDec", "DPTNWavEncDec"]
 
 
@@ -9,7 +9,7 @@ def __getattr__(name):  # torch-dependent parts are imported lazily (spec.py sta
     if name == "DptnEngine":
         from .engine import DptnEngine
         return DptnEngine
-    if name in ("DPTNAVWavEncDec", "DPTNWavEncDec"):
+    if name in ("DPTNAVWavEncDec", "DPTNWavEncDec", "DPRNNEncDec", "DPRNNAVEncDec"):
         from . import model
         return getattr(model, name)
     raise AttributeError(name)

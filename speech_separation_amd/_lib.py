@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdptnav.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class DptnavConfig(C.Structure):
@@ -20,7 +20,7 @@ class DptnavConfig(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "num_features", "video_emb_size", "hidden_video", "kernel_size_enc", "hidden_dim", "num_blocks",
-        "chunk_size", "step_size", "num_heads", "bidir", "audio_only")]
+        "chunk_size", "step_size", "num_heads", "bidir", "audio_only", "arch")]
 
 
 _vp, _fp, _i, _i64, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_size_t

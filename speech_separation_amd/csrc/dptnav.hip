@@ -170,12 +170,15 @@ void build_names(dptnav_ctx* c) {
       const std::string pre =
           "dprnn.model." + std::to_string(b) + (p == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
       const int ndir = (p == 0 || g.bidir) ? 2 : 1;
-      add(pre + "mha.in_proj_weight", 3 * N * N);
-      add(pre + "mha.in_proj_bias", 3 * N);
-      add(pre + "mha.out_proj.weight", N * N);
-      add(pre + "mha.out_proj.bias", N);
-      add(pre + "ln1.weight", N);
-      add(pre + "ln1.bias", N);
+      const bool dptn = g.arch == 0;
+      if (dptn) {
+        add(pre + "mha.in_proj_weight", 3 * N * N);
+        add(pre + "mha.in_proj_bias", 3 * N);
+        add(pre + "mha.out_proj.weight", N * N);
+        add(pre + "mha.out_proj.bias", N);
+        add(pre + "ln1.weight", N);
+        add(pre + "ln1.bias", N);
+      }
       add(pre + "rnn.weight_ih_l0", 4 * H * N);
       add(pre + "rnn.weight_hh_l0", 4 * H * H);
       add(pre + "rnn.bias_ih_l0", 4 * H);
@@ -186,10 +189,10 @@ void build_names(dptnav_ctx* c) {
         add(pre + "rnn.bias_ih_l0_reverse", 4 * H);
         add(pre + "rnn.bias_hh_l0_reverse", 4 * H);
       }
-      add(pre + "ffn.1.weight", N * H * ndir);
-      add(pre + "ffn.1.bias", N);
-      add(pre + "ln2.weight", N);
-      add(pre + "ln2.bias", N);
+      add(pre + (dptn ? "ffn.1.weight" : "fc.weight"), N * H * ndir);
+      add(pre + (dptn ? "ffn.1.bias" : "fc.bias"), N);
+      add(pre + (dptn ? "ln2.weight" : "norm1d.weight"), N);
+      add(pre + (dptn ? "ln2.bias" : "norm1d.bias"), N);
     }
   add("dprnn.speakers_separation.0.weight", 1);
   add("dprnn.speakers_separation.1.weight", 2 * N * N);
@@ -205,12 +208,15 @@ PathWeights path_weights(const dptnav_ctx* c, int block, int path) {
       "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
   PathWeights p{};
   p.ndir = (path == 0 || c->cfg.bidir) ? 2 : 1;
-  p.in_w = c->w(pre + "mha.in_proj_weight");
-  p.in_b = c->w(pre + "mha.in_proj_bias");
-  p.out_w = c->w(pre + "mha.out_proj.weight");
-  p.out_b = c->w(pre + "mha.out_proj.bias");
-  p.ln1_w = c->w(pre + "ln1.weight");
-  p.ln1_b = c->w(pre + "ln1.bias");
+  const bool dptn = c->cfg.arch == 0;
+  if (dptn) {
+    p.in_w = c->w(pre + "mha.in_proj_weight");
+    p.in_b = c->w(pre + "mha.in_proj_bias");
+    p.out_w = c->w(pre + "mha.out_proj.weight");
+    p.out_b = c->w(pre + "mha.out_proj.bias");
+    p.ln1_w = c->w(pre + "ln1.weight");
+    p.ln1_b = c->w(pre + "ln1.bias");
+  }
   p.w_ih[0] = c->w(pre + "rnn.weight_ih_l0");
   p.w_hh[0] = c->w(pre + "rnn.weight_hh_l0");
   p.b_ih[0] = c->w(pre + "rnn.bias_ih_l0");
@@ -226,10 +232,10 @@ PathWeights path_weights(const dptnav_ctx* c, int block, int path) {
     p.b_ih[1] = p.b_ih[0];
     p.b_hh[1] = p.b_hh[0];
   }
-  p.ffn_w = c->w(pre + "ffn.1.weight");
-  p.ffn_b = c->w(pre + "ffn.1.bias");
-  p.ln2_w = c->w(pre + "ln2.weight");
-  p.ln2_b = c->w(pre + "ln2.bias");
+  p.ffn_w = c->w(pre + (dptn ? "ffn.1.weight" : "fc.weight"));
+  p.ffn_b = c->w(pre + (dptn ? "ffn.1.bias" : "fc.bias"));
+  p.ln2_w = c->w(pre + (dptn ? "ln2.weight" : "norm1d.weight"));
+  p.ln2_b = c->w(pre + (dptn ? "ln2.bias" : "norm1d.bias"));
   return p;
 }
 
@@ -242,11 +248,15 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
     return c->fail(DPTNAV_ERR_INVALID, "T=%lld gives L=%lld frames < chunk_size=%d", (long long)T, (long long)p->L,
                    g.chunk_size);
   p->S = (p->L - g.chunk_size) / g.step_size + 1;
-  if (p->S > 256 || g.chunk_size > 256)
+  if (g.arch == 0 && (p->S > 256 || g.chunk_size > 256))
     return c->fail(DPTNAV_ERR_INVALID, "sequence length > 256 unsupported by the attention kernel (S=%lld, K=%d)",
                    (long long)p->S, g.chunk_size);
-  if ((int64_t)B * p->S * g.chunk_size * 3 * N >= ((int64_t)1 << 31))
-    return c->fail(DPTNAV_ERR_INVALID, "batch too large for 32-bit token indexing (B=%d)", B);
+  {  // token indices are 32-bit inside the kernels: (tokens + dump rows) x widest row must stay below 2^31
+    const int64_t widest = std::max<int64_t>(3 * N, 2 * H);
+    if (((int64_t)B + 1) * p->S * g.chunk_size * widest >= ((int64_t)1 << 31))
+      return c->fail(DPTNAV_ERR_INVALID, "batch too large for 32-bit token indexing (B=%d, %lld tokens per mixture)",
+                     B, (long long)(p->S * g.chunk_size));
+  }
   p->M = (int64_t)B * p->S * g.chunk_size;
   const int64_t nst_a = ((int64_t)B * p->S + 31) / 32, nst_e = ((int64_t)B * g.chunk_size + 31) / 32;
   const int64_t pre_tiles = std::max(nst_a * g.chunk_size, nst_e * p->S);
@@ -367,24 +377,27 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const SeqGeom geom = make_geom(path, B, S, K);
   float *qkv = ws + pl.qkv, *att = ws + pl.att, *y1 = ws + pl.y1, *pre = ws + pl.pre, *hc = ws + pl.hc;
   const int64_t ntiles = (M + BM - 1) / BM;
+  const bool dptn = g.arch == 0;
+  const float* lstm_in = dptn ? y1 : x_in;   // DPRNN feeds the chunk tokens straight into the LSTM (dprnn.py:37-40)
 
   // K1: qkv = x W_in^T + b_in                                  (nn.MultiheadAttention in-projection)
-  {
+  if (dptn) {
     ALoadDense al{x_in, M, N, BM};
     EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
     if (int rc = launch_gemm<N, 3, WR, WC>(c, run, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, al, ep)) return rc;
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
-  if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
+  if (dptn)
+    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
-  {
+  if (dptn) {
     ALoadDense al{att, M, N, BM};
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
     if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
   }
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
-    ALoadSeqTile al{y1, N, geom};
+    ALoadSeqTile al{lstm_in, N, geom};
     EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
     if (int rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]))
@@ -400,11 +413,23 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                       w.ndir * LSTM_H, (int)M, geom, stamps);
+                       w.ndir * LSTM_H, (int)M, geom, stamps, c->cfg.arch == 0 ? 1 : 0);
     LAUNCH_CHECK(c, "lstm");
   }
   if (run.lstm_record && hipEventRecord(run.lstm_record, st) != hipSuccess)
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger record");
+  // K6 (DPRNN): x_out = LayerNorm(h W_fc^T + b_fc) + x_in       (dprnn.py:41-45, 83-87)
+  if (!dptn) {
+    EpiBiasLNRes<GROUP> ep{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM};
+    if (w.ndir == 2) {
+      ALoadDense al{hc, M, 2 * LSTM_H, BM};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else {
+      ALoadDense al{hc, M, LSTM_H, BM};
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    }
+    return DPTNAV_OK;
+  }
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
   {
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
@@ -528,10 +553,12 @@ int dptnav_create(const dptnav_config* cfg, dptnav_handle* out) {
   *out = nullptr;
   if (cfg->num_features != 128 && cfg->num_features != 64) return bad("num_features must be 128 or 64");
   if (cfg->hidden_dim != 128) return bad("hidden_dim must be 128");
-  if (cfg->num_heads != 4) return bad("num_heads must be 4 (head dim 32 or 16)");
+  if (cfg->arch != 0 && cfg->arch != 1) return bad("arch must be 0 (DPTN) or 1 (DPRNN)");
+  if (cfg->arch == 0 && cfg->num_heads != 4) return bad("num_heads must be 4 (head dim 32 or 16)");
   if (cfg->kernel_size_enc < 2 || cfg->kernel_size_enc > 8) return bad("kernel_size_enc must be in [2,8]");
   if (cfg->num_blocks < 1) return bad("num_blocks must be >= 1");
-  if (cfg->chunk_size < 1 || cfg->chunk_size > 256) return bad("chunk_size must be in [1,256]");
+  if (cfg->chunk_size < 1 || (cfg->arch == 0 && cfg->chunk_size > 256))
+    return bad("chunk_size must be in [1,256] (attention kernel limit; DPRNN has none)");
   if (cfg->step_size < 1 || cfg->step_size > cfg->chunk_size) return bad("step_size must be in [1,chunk_size]");
   if (!cfg->audio_only) {
     if (cfg->hidden_video != cfg->num_features) return bad("hidden_video must equal num_features");
@@ -805,7 +832,8 @@ double dptnav_flops_per_mixture(dptnav_handle h, int64_t T) {
   const double N = g.num_features, H = g.hidden_dim, K = g.chunk_size;
   const double L = (double)dptnav_frames(h, T), S = (double)dptnav_chunks(h, T), M = S * K;
   auto path = [&](double len, double ndir) {
-    return 2 * N * 3 * N + 2 * N * N + 4 * len * N + ndir * (2 * N * 4 * H + 2 * H * 4 * H) + 2 * ndir * H * N;
+    const double rnn = ndir * (2 * N * 4 * H + 2 * H * 4 * H) + 2 * ndir * H * N;
+    return g.arch == 0 ? 2 * N * 3 * N + 2 * N * N + 4 * len * N + rnn : rnn;
   };
   double f = g.num_blocks * M * (path(K, 2) + path(S, g.bidir ? 2 : 1));
   f += 2 * N * 2 * N * M;                 // separation conv

@@ -281,6 +281,43 @@ struct EpiBiasResLN {
   }
 };
 
+// y = LayerNorm(v + bias) + residual  (DPRNN: norm BEFORE the residual add, dprnn.py:41-45, 83-87)
+template <int GROUP>
+struct EpiBiasLNRes {
+  static constexpr bool DIRECT = false;
+  float* out;
+  const float* bias;
+  const float* res;    // [M][ld]
+  const float* gamma;
+  const float* beta;
+  int64_t M;
+  int ld;
+  int bm;
+  DEV float4 prefetch(int tile, int row, int c4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    const float s = group_sum<GROUP>((v.x + v.y) + (v.z + v.w));
+    const float mu = s * (1.0f / (4 * GROUP));
+    const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+    const float q = group_sum<GROUP>((dx * dx + dy * dy) + (dz * dz + dw * dw));
+    const float rstd = rsqrtf(q * (1.0f / (4 * GROUP)) + 1e-5f);
+    if (r >= M) return;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + 4 * c4);
+    float4 y;
+    y.x = dx * rstd * ga.x + be.x + x.x;
+    y.y = dy * rstd * ga.y + be.y + x.y;
+    y.z = dz * rstd * ga.z + be.z + x.z;
+    y.w = dw * rstd * ga.w + be.w + x.w;
+    *reinterpret_cast<float4*>(out + r * ld + 4 * c4) = y;
+  }
+};
+
 // LSTM pre-activations straight from the accumulators into the fragment layout (common.h)
 struct EpiLstmPre {
   static constexpr bool DIRECT = true;

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
                                                                const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b,
                                                                float* __restrict__ hc, int ldh, int dump_row,
-                                                               SeqGeom g, unsigned long long* __restrict__ stamps) {
+                                                               SeqGeom g, unsigned long long* __restrict__ stamps,
+                                                               int relu_out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                      // [2][32][LSTM_LDH]
   float* Ps = smem + LSTM_HS_FLOATS;     // [4 waves][16 pieces][64 lanes][4]
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int q = st * 32 + ROW32(r, hh);
-    const int tokb = q < g.nseq ? (int)seq_token_base(g, q) : dump_row;
-    oidx[r] = (unsigned)((tokb + t0 * tstride) * ldh + outcol);
+    const unsigned tokb = q < g.nseq ? (unsigned)seq_token_base(g, q) : (unsigned)dump_row;
+    oidx[r] = (tokb + (unsigned)(t0 * tstride)) * (unsigned)ldh + (unsigned)outcol;   // < 2^32, checked by the host
   }
 
   for (int i = tid; i < 32 * LSTM_LDH; i += 256) Hs[i] = 0.f;  // h_{-1} = 0 (buffer 0)
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
       cst[r] = cn;
       const float hn = og * fast_tanh(cn);
       hnext[ROW32(r, hh) * LSTM_LDH + 32 * w + c] = hn;
-      hout[r] = fmaxf(hn, 0.f);
+      hout[r] = relu_out ? fmaxf(hn, 0.f) : hn;   // DPTN feeds ffn = ReLU -> Linear; DPRNN feeds fc directly
     }
     if (STAMP) c3 = __builtin_amdgcn_s_memtime();
     __syncthreads();

@@ -41,7 +41,7 @@ class DptnEngine:
         self.lib = _lib.load()
         c = _lib.DptnavConfig(cfg.num_features, cfg.video_emb_size, cfg.hidden_video, cfg.kernel_size_enc,
                               cfg.hidden_dim, cfg.num_blocks, cfg.chunk_size, cfg.step_size, cfg.num_heads,
-                              int(cfg.bidir), int(cfg.audio_only))
+                              int(cfg.bidir), int(cfg.audio_only), {"dptn": 0, "dprnn": 1}[cfg.arch])
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self.lib.dptnav_create(C.byref(c), C.byref(h))

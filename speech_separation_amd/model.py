@@ -49,9 +49,9 @@ def _init_like_torch(key: str, p: torch.Tensor, cfg: DPTNConfig) -> None:
         elif ".rnn." in key:
             b = 1.0 / math.sqrt(cfg.hidden_dim)
             p.uniform_(-b, b)
-        elif leaf2 in ("ln1.weight", "ln2.weight", "video_ln.weight"):
+        elif leaf2 in ("ln1.weight", "ln2.weight", "video_ln.weight", "norm1d.weight"):
             p.fill_(1.0)
-        elif leaf2 in ("ln1.bias", "ln2.bias", "video_ln.bias", "mha.in_proj_bias", "out_proj.bias"):
+        elif leaf2 in ("ln1.bias", "ln2.bias", "video_ln.bias", "norm1d.bias", "mha.in_proj_bias", "out_proj.bias"):
             p.zero_()
         elif leaf2 == "mha.in_proj_weight":
             nn.init.xavier_uniform_(p)
@@ -60,7 +60,8 @@ def _init_like_torch(key: str, p: torch.Tensor, cfg: DPTNConfig) -> None:
             b = 1.0 / math.sqrt(fan_in)
             p.uniform_(-b, b)
         else:  # biases of Linear / Conv: U(+-1/sqrt(fan_in of the matching weight))
-            fan_in = {"visual_compression.bias": cfg.video_emb_size, "ffn.1.bias": None}.get(leaf2, cfg.num_features)
+            fan_in = {"visual_compression.bias": cfg.video_emb_size, "ffn.1.bias": None, "fc.bias": None}.get(
+                leaf2, cfg.num_features)
             if fan_in is None:
                 fan_in = cfg.hidden_dim * (2 if (cfg.bidir or "intra_chunk_block" in key) else 1)
             b = 1.0 / math.sqrt(fan_in)
@@ -146,3 +147,34 @@ class DPTNWavEncDec(_DPTNBase):
 
     def forward(self, mix, **batch):
         return self._run(mix, None, None)
+
+
+class DPRNNEncDec(_DPTNBase):
+    """Audio-only DPRNN (backbone of BASELINE config 5) -- same constructor as the reference class of that name
+    (src/model/dprnn.py:238-247); forward(mix, **batch) as dprnn.py:260."""
+
+    def __init__(self, num_features=64, kernel_size_enc=2, hidden_dim=32, num_blocks=6, chunk_size=10, step_size=5,
+                 bidir=True):
+        super().__init__(DPTNConfig(num_features=num_features, hidden_video=num_features,
+                                    kernel_size_enc=kernel_size_enc, hidden_dim=hidden_dim, num_blocks=num_blocks,
+                                    chunk_size=chunk_size, step_size=step_size, bidir=bool(bidir), audio_only=True,
+                                    arch="dprnn"))
+
+    def forward(self, mix, **batch):
+        return self._run(mix, None, None)
+
+
+class DPRNNAVEncDec(_DPTNBase):
+    """"DPRNN-AV" of BASELINE config 5.  The reference has no such class; this is
+    DPRNNEncDec plus the lip-embedding fusion head of DPTNAVWavEncDec (dptn_wav.py:173-184) with the same parameter
+    names (gate, visual_compression.*, video_ln.*)."""
+
+    def __init__(self, num_features=64, video_emb_size=512, hidden_video=64, kernel_size_enc=2, hidden_dim=32,
+                 num_blocks=6, chunk_size=10, step_size=5, bidir=True):
+        super().__init__(DPTNConfig(num_features=num_features, video_emb_size=video_emb_size,
+                                    hidden_video=hidden_video, kernel_size_enc=kernel_size_enc,
+                                    hidden_dim=hidden_dim, num_blocks=num_blocks, chunk_size=chunk_size,
+                                    step_size=step_size, bidir=bool(bidir), audio_only=False, arch="dprnn"))
+
+    def forward(self, mix, s1_embedding, s2_embedding, **batch):
+        return self._run(mix, s1_embedding, s2_embedding)

@@ -28,7 +28,7 @@ def test_no_cpu_path_without_gpu():
     import ctypes as C
     lib = _lib.load()
     h = C.c_void_p()
-    cfg = _lib.DptnavConfig(128, 512, 128, 7, 128, 6, 150, 75, 4, 1, 0)
+    cfg = _lib.DptnavConfig(128, 512, 128, 7, 128, 6, 150, 75, 4, 1, 0, 0)
     assert lib.dptnav_create(C.byref(cfg), C.byref(h)) != 0
     assert b"no CPU path" in lib.dptnav_last_error(None)
     from speech_separation_amd.engine import DptnEngine
@@ -82,6 +82,18 @@ def test_module_is_a_dropin_for_the_reference_class():
     a = DPTNWavEncDec(num_features=64, kernel_size_enc=7, hidden_dim=128, num_blocks=6, chunk_size=150, step_size=75,
                       num_heads=4, dropout=0.1, bidir=True)                            # dptn_wav.yaml
     assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == state_dict_spec(DPTN_AUDIO)
+
+
+def test_dprnn_dropin_state_dict():
+    from speech_separation_amd import DPRNNAVEncDec, DPRNNEncDec
+    from speech_separation_amd.spec import DPRNN_AUDIO, DPRNN_AV
+    m = DPRNNEncDec(num_features=64, kernel_size_enc=2, hidden_dim=128, num_blocks=6, chunk_size=250, step_size=125,
+                    bidir=True)                                                    # src/configs/model/dprnn.yaml
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == state_dict_spec(DPRNN_AUDIO)
+    assert sum(p.numel() for p in m.parameters()) == 2_595_521                      # paper.tex "2.6 M"
+    av = DPRNNAVEncDec(num_features=64, hidden_video=64, kernel_size_enc=2, hidden_dim=128, num_blocks=6,
+                       chunk_size=250, step_size=125)
+    assert [(k, tuple(v.shape)) for k, v in av.state_dict().items()] == state_dict_spec(DPRNN_AV)
 
 
 def test_product_code_never_imports_the_oracle():
