@@ -629,14 +629,17 @@ int64_t dptnav_chunks(dptnav_handle h, int64_t T) {
 
 size_t dptnav_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
   if (!h) return 0;
+  // dptnav_forward (option overlap=1) splits B >= 2 into two independently planned halves; the stage entry
+  // points and overlap=0 use one plan for the whole batch.  The workspace covers whichever of the two is valid/larger.
   Plan pl;
-  if (make_plan(h, B, T, Tv, &pl)) return 0;
-  size_t need = pl.total;
-  if (B >= 2) {   // dptnav_forward splits the batch into two independently planned halves
+  size_t need = 0;
+  if (make_plan(h, B, T, Tv, &pl) == DPTNAV_OK) need = pl.total;
+  if (B >= 2) {
     Plan a, b;
-    if (make_plan(h, (B + 1) / 2, T, Tv, &a) || make_plan(h, B / 2, T, Tv, &b)) return 0;
-    const size_t two = ((a.total + 63) & ~(size_t)63) + ((b.total + 63) & ~(size_t)63);
-    if (two > need) need = two;
+    if (make_plan(h, (B + 1) / 2, T, Tv, &a) == DPTNAV_OK && make_plan(h, B / 2, T, Tv, &b) == DPTNAV_OK) {
+      const size_t two = ((a.total + 63) & ~(size_t)63) + ((b.total + 63) & ~(size_t)63);
+      if (two > need) need = two;
+    }
   }
   return need * sizeof(float);
 }
