@@ -119,6 +119,17 @@ int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, f
 int dptnav_stage_tail(dptnav_handle h, const float* x, const float* encoded, int B, int64_t T, float* s1_pred,
                       float* s2_pred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- loss / metric statistics --------------------------------------------------------------------
+ * replaces the arithmetic of SiSNRLoss.forward (src/loss/ss_losses.py:100-114) and of the four + two
+ * ScaleInvariantSignalNoiseRatio calls of SISNRiMetric / SS2BaseMetric (src/metrics/si_snri.py:12-30,
+ * src/metrics/base_metric.py:41-60), which cost the reference >= 6 device->host syncs per batch.
+ *   all inputs (B,T) fp32 on the device; out (B,6,2) fp32 on the device:
+ *   pair order (s1_pred,s1) (s1_pred,s2) (s2_pred,s1) (s2_pred,s2) (mix,s1) (mix,s2);
+ *   [..][0] = SI-SNR in dB with torchmetrics' eps convention, [..][1] = the reference loss term -20 log10(.) (no eps).
+ * Batch means and the batch-level PIT are a few flops on 12*B numbers: speech_separation_amd/metrics.py. */
+int dptnav_sisnr_pairs(dptnav_handle h, const float* s1_pred, const float* s2_pred, const float* s1, const float* s2,
+                       const float* mix, int B, int64_t T, float* out, void* stream);
+
 /* ---- introspection for tests / profiling ------------------------------------------------ */
 /* Offsets (in bytes, from the workspace base) of intermediates left behind by the LAST
  * dptnav_stage_path call: "qkv" (M,3N), "att" (M,N), "y1" (M,N) [post-LN1], "hc" (M,2H)

@@ -42,6 +42,7 @@ SYMBOLS = {
     "dptnav_stage_head": (_i, [_vp, _fp, _fp, _fp, _i, _i64, _i, _fp, _fp, _vp, _sz, _vp]),
     "dptnav_stage_path": (_i, [_vp, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp]),
     "dptnav_stage_tail": (_i, [_vp, _fp, _fp, _i, _i64, _fp, _fp, _vp, _sz, _vp]),
+    "dptnav_sisnr_pairs": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _fp, _vp]),
     "dptnav_workspace_tap": (_i, [_vp, _i, _i64, _i, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
     "dptnav_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dptnav_profile_enable": (_i, [_vp, _i]),

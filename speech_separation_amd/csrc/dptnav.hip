@@ -15,6 +15,7 @@
 #include "gemm_ws.h"
 #include "headtail.h"
 #include "lstm.h"
+#include "sisnr.h"
 
 namespace {
 
@@ -783,6 +784,18 @@ int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* 
   else if (n == "encoded") { *off = pl.E * 4; *numel = (size_t)B * pl.L * h->cfg.num_features; }
   else if (n == "lstm_stamps") { *off = pl.stamps * 4; *numel = (pl.total - pl.stamps); }
   else return h->fail(DPTNAV_ERR_INVALID, "unknown tap '%s'", name);
+  return DPTNAV_OK;
+}
+
+// ---- loss / metric statistics (A10, A11): one launch, the caller does ONE device->host copy of 12*B floats ----
+int dptnav_sisnr_pairs(dptnav_handle h, const float* s1_pred, const float* s2_pred, const float* s1, const float* s2,
+                       const float* mix, int B, int64_t T, float* out, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!s1_pred || !s2_pred || !s1 || !s2 || !mix || !out || B < 1 || T < 2)
+    return h->fail(DPTNAV_ERR_INVALID, "sisnr_pairs: bad argument");
+  hipLaunchKernelGGL(sisnr_pairs_kernel, dim3(B, 6), dim3(256), 0, (hipStream_t)stream, s1_pred, s2_pred, s1, s2, mix, T,
+                     out);
+  LAUNCH_CHECK(h, "sisnr_pairs");
   return DPTNAV_OK;
 }
 

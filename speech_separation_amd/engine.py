@@ -178,6 +178,18 @@ class DptnEngine:
             self._raise(rc, "dptnav_forward")
         return s1, s2
 
+    # ------------------------------------------------------------------ loss / metric statistics
+    def sisnr_pairs(self, s1_pred, s2_pred, s1, s2, mix) -> torch.Tensor:
+        """(B,6,2) device tensor: [metric dB, loss term] for the pairs (p1,s1) (p1,s2) (p2,s1) (p2,s2) (mix,s1) (mix,s2)."""
+        B, T = mix.shape
+        ts = [_check(t, n, (B, T), self.device) for t, n in ((s1_pred, "s1_pred"), (s2_pred, "s2_pred"), (s1, "s1"),
+                                                             (s2, "s2"), (mix, "mix"))]
+        out = torch.empty(B, 6, 2, device=self.device)
+        rc = self.lib.dptnav_sisnr_pairs(self._h, *[t.data_ptr() for t in ts], B, T, out.data_ptr(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_sisnr_pairs")
+        return out
+
     # ------------------------------------------------------------------ stages (parity tests / profiling)
     def stage_head(self, mix, e1=None, e2=None):
         cfg = self.cfg

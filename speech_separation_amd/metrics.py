@@ -1,0 +1,70 @@
+"""Loss value and SI-SNR(i) metrics computed on the GPU with ONE kernel launch and ONE device->host copy.
+
+Mirrors (does not import) the reference interfaces that consume the model's outputs:
+  * ``SiSNRWavLoss()(**batch) -> {"loss": tensor}``          src/loss/ss_losses.py:117-130 (+ BaseSSLoss :21-26)
+  * ``SISNRiMetric(name=..., device=...)(**batch) -> value``  src/metrics/si_snri.py:7-30
+  * ``SISNRMetric(name=..., device=...)(**batch) -> value``   src/metrics/si_snr.py:6-12
+Both resolve the speaker permutation at BATCH level (compare the two batch means), exactly as the reference does
+(ss_losses.py:21-25, base_metric.py:57-60) -- this is not per-utterance PIT.
+
+The reference needs >= 6 ``.item()`` syncs per batch for this (base_metric.py:53-56, si_snri.py:25-26); here the
+per-item statistics come from ``dptnav_sisnr_pairs`` and the 12*B numbers are reduced on the host.
+Forward values only (evaluation / logging): the training loss with gradients belongs to the backward work that
+is not built yet.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .engine import DptnEngine
+from .spec import DPTN_AV
+
+_ENGINES: Dict[torch.device, DptnEngine] = {}
+
+
+def _engine(device: torch.device) -> DptnEngine:
+    if device.type != "cuda":
+        raise RuntimeError("speech_separation_amd.metrics computes on an AMD GPU through libdptnav; there is no CPU path")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device not in _ENGINES:
+        _ENGINES[device] = DptnEngine(DPTN_AV, device)   # the statistics kernel needs a handle, not weights
+    return _ENGINES[device]
+
+
+def pair_statistics(s1_pred, s2_pred, s1, s2, mix) -> torch.Tensor:
+    """(6,2) CPU tensor of BATCH MEANS: rows = (p1,s1) (p1,s2) (p2,s1) (p2,s2) (mix,s1) (mix,s2);
+    columns = (SI-SNR dB, reference loss term).  One launch, one sync."""
+    stats = _engine(mix.device).sisnr_pairs(s1_pred, s2_pred, s1, s2, mix)
+    return stats.double().mean(0).cpu()
+
+
+class SiSNRWavLoss:
+    """Forward value of the reference's PIT SI-SNR loss (batch-level permutation, -20 log10, no eps)."""
+
+    def __call__(self, s1_pred, s2_pred, s1, s2, mix=None, **batch):
+        m = pair_statistics(s1_pred, s2_pred, s1, s2, s1_pred if mix is None else mix)[:, 1]
+        perm1 = (m[0] + m[3]) / 2
+        perm2 = (m[1] + m[2]) / 2
+        return {"loss": perm2 if perm2 < perm1 else perm1}
+
+
+class SISNRMetric:
+    def __init__(self, name=None, device="cuda", lower_better=False, *args, **kwargs):
+        self.name = name if name is not None else type(self).__name__
+        self.pick = min if lower_better else max
+
+    def _pit(self, m):
+        return self.pick(float((m[0] + m[3]) / 2), float((m[1] + m[2]) / 2))
+
+    def __call__(self, s1_pred, s2_pred, s1, s2, mix=None, **batch):
+        m = pair_statistics(s1_pred, s2_pred, s1, s2, s1_pred if mix is None else mix)[:, 0]
+        return self._pit(m)
+
+
+class SISNRiMetric(SISNRMetric):
+    def __call__(self, s1_pred, s2_pred, s1, s2, mix, **batch):
+        m = pair_statistics(s1_pred, s2_pred, s1, s2, mix)[:, 0]
+        return torch.tensor(self._pit(m) - float((m[4] + m[5]) / 2))   # 0-dim tensor like the reference (float - tensor)
