@@ -1,0 +1,53 @@
+"""Host-side data path either side of the forward (formats restated from the reference, see speech_separation_amd/io.py)."""
+import os
+
+import numpy as np
+import torch
+
+from speech_separation_amd.io import PinnedBatcher, collate, load_object, save_predictions
+
+
+def _items(tmp_path, n=3, T=64):
+    rng = np.random.default_rng(0)
+    items = []
+    for i in range(n):
+        e = rng.standard_normal((512, 50)).astype(np.float32)
+        p = os.path.join(tmp_path, f"emb{i}.npz")
+        np.savez_compressed(p, embedding=e)                       # make_embeddings.py:69
+        items.append({"mix": torch.randn(1, T), "s1": torch.randn(1, T), "s2": torch.randn(1, T),
+                      "s1_embedding": load_object(p), "s2_embedding": load_object(p), "s1_video": None,
+                      "mix_spectrogram": torch.randn(1, 8, 5), "audio_path": f"/data/mix/utt{i}.wav"})
+        assert items[-1]["s1_embedding"].shape == (1, 512, 50) and np.array_equal(items[-1]["s1_embedding"][0].numpy(), e)
+    return items
+
+
+def test_collate_semantics(tmp_path):
+    items = _items(str(tmp_path))
+    b = collate(items)
+    assert b["mix"].shape == (3, 64) and b["s1_embedding"].shape == (3, 512, 50) and b["mix_spectrogram"].shape == (3, 8, 5)
+    assert b["s1_video"] is None and b["audio_path"] == [f"/data/mix/utt{i}.wav" for i in range(3)]
+    assert "s2_video" not in b
+    assert torch.equal(b["s2"][1], items[1]["s2"][0])
+
+
+def test_pinned_batcher_equals_collate_on_cpu(tmp_path):
+    items = _items(str(tmp_path))
+    want = collate(items)
+    got = PinnedBatcher("cpu").to_device(items)
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert (got[k] is None and v is None) or (isinstance(v, list) and got[k] == v) or torch.equal(got[k], v)
+
+
+def test_prediction_files_have_the_reference_layout(tmp_path):
+    items = _items(str(tmp_path))
+    b = collate(items)
+    b["s1_pred"], b["s2_pred"] = b["s1"] * 2, b["s2"] * 3
+    paths = save_predictions(b, str(tmp_path / "saved" / "val"))
+    assert [os.path.basename(p) for p in paths] == ["utt0.pth", "utt1.pth", "utt2.pth"]
+    d = torch.load(paths[1])
+    assert set(d) == {"s1_pred", "s2_pred", "s1_true", "s2_true"} and d["s1_pred"].shape == (64,)
+    assert torch.equal(d["s2_pred"], b["s2"][1] * 3) and torch.equal(d["s1_true"], b["s1"][1])
+    b["s1"] = b["s2"] = None                                       # no ground truth: only the predictions are written
+    d = torch.load(save_predictions(b, str(tmp_path / "saved" / "test"))[0])
+    assert set(d) == {"s1_pred", "s2_pred"}
