@@ -136,6 +136,22 @@ int dptnav_sisnr_pairs(dptnav_handle h, const float* s1_pred, const float* s2_pr
  * [ReLU(h_fwd|h_bwd)].  Returns non-zero for an unknown name. */
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* offset_bytes,
                          size_t* numel);
+/* ---- training step, path level (BASELINE config 4; DPTN architecture, num_features = 128, dropout 0) ------------
+ * The backward of one TransformerDPRNN (what torch.autograd derives from dptn.py:36-52 in the reference's
+ * loss.backward(), src/trainer/trainer.py:47).  The forward variant keeps on a caller-provided tape what the backward
+ * needs (qkv, attention output, LayerNorm-1 output, raw LSTM output, post-activation gates and cell states);
+ * attention probabilities and the pre-LayerNorm activations are recomputed.  Parameter gradients are WRITTEN (not
+ * accumulated) to the buffers bound with dptnav_bind_grads (same slot order as dptnav_bind_weights).
+ *   x_in, x_out, d_out, d_in: (B,S,K,N) token layout; d_in may not alias d_out. */
+int dptnav_bind_grads(dptnav_handle h, float* const* dev_ptrs, int n);
+size_t dptnav_train_path_tape_bytes(dptnav_handle h, int B, int S);
+size_t dptnav_train_bwd_workspace_bytes(dptnav_handle h, int B, int S);
+int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S,
+                              void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
+                               int B, int S, void* tape, size_t tape_bytes, void* bwd_workspace,
+                               size_t bwd_workspace_bytes, void* stream);
+
 /* Tuning / diagnostic knobs (never needed for correct results).  Keys:
  *   "overlap" (0/1, default 1): dptnav_forward runs the batch as two halves on two internal streams (forked from
  *                 and joined to the caller's stream by events) so that one half's GEMM/attention launches fill the

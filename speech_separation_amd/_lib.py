@@ -44,6 +44,11 @@ SYMBOLS = {
     "dptnav_stage_tail": (_i, [_vp, _fp, _fp, _i, _i64, _fp, _fp, _vp, _sz, _vp]),
     "dptnav_sisnr_pairs": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _fp, _vp]),
     "dptnav_workspace_tap": (_i, [_vp, _i, _i64, _i, C.c_char_p, C.POINTER(_sz), C.POINTER(_sz)]),
+    "dptnav_bind_grads": (_i, [_vp, C.POINTER(_fp), _i]),
+    "dptnav_train_path_tape_bytes": (_sz, [_vp, _i, _i]),
+    "dptnav_train_bwd_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "dptnav_train_path_forward": (_i, [_vp, _i, _i, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "dptnav_train_path_backward": (_i, [_vp, _i, _i, _fp, _fp, _fp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "dptnav_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dptnav_profile_enable": (_i, [_vp, _i]),
     "dptnav_profile_collect": (_i, [_vp]),

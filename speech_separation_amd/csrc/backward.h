@@ -1,0 +1,482 @@
+// backward.h -- parameter-gradient building blocks of the training step (BASELINE config 4), fp32, gfx950.
+//
+//   wgrad_kernel     dW[NN][KK] = sum over tokens  dY[m][0:NN]^T  X[m][0:KK]     (a GEMM whose K dimension is the
+//                    3.4e5 tokens and whose output is tiny): every workgroup accumulates its share of 32-token tiles
+//                    in MFMA accumulators and writes ONE partial tile to a slab; slab_reduce_kernel sums the slabs in
+//                    a fixed order -> bit-reproducible, no float atomics.
+//   colsum_kernel    bias gradients: column sums of dY over the tokens, same slab scheme.
+#pragma once
+#include "common.h"
+#include "gemm_ws.h"
+#include "lstm.h"
+
+// rows of a token-major matrix shifted by `shift` positions along the sequence (h_{t-1} for the W_hh gradient):
+// row r of the logical matrix is token r; the loader returns the row of the token `shift` positions earlier in the
+// same sequence, zeros at the sequence boundary.
+struct ALoadSeqShift {
+  const float* A;   // [M][lda]
+  int64_t M;
+  int lda, col0, bm;
+  int shift;        // +1: previous position (forward direction), -1: next position (reverse direction)
+  SeqGeom g;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    // token -> (sequence, position)
+    int pos;
+    int64_t src;
+    if (g.mode == 0) {               // intra: token = q*K + k
+      pos = (int)(r % g.K);
+      src = r - shift;
+    } else {                         // inter: token = (b*S + s)*K + k, position s
+      pos = (int)((r / g.K) % g.S);
+      src = r - (int64_t)shift * g.K;
+    }
+    const int p2 = pos - shift;
+    if (p2 < 0 || p2 >= g.len) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(A + src * lda + col0 + 4 * k4);
+  }
+};
+
+// dense rows of a column slice [col0, col0 + width) of a token-major matrix
+struct ALoadCols {
+  const float* A;
+  int64_t M;
+  int lda, col0, bm;
+  bool relu;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(A + r * lda + col0 + 4 * k4);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+  }
+};
+
+template <int NN, int KK>
+struct WgradShape {
+  static constexpr int LDY = NN + 4, LDX = KK + 4;
+  static constexpr int RB = NN / 128;          // 32-row blocks of dW owned by one wave
+  static constexpr int CB = KK / 32;           // 32-column blocks (every wave owns all of them)
+  static constexpr size_t lds_bytes() { return sizeof(float) * (4 + 32 * (size_t)(LDY + LDX)); }
+};
+
+// grid.x workgroups; slab[blockIdx.x][NN][KK] receives the partial sum of this workgroup's tiles.
+template <int NN, int KK, class YLoad, class XLoad>
+__global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __restrict__ queue, YLoad yl, XLoad xl,
+                                                     float* __restrict__ slab) {
+  using Sh = WgradShape<NN, KK>;
+  static_assert(NN % 128 == 0 && KK % 32 == 0, "wgrad tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_next = reinterpret_cast<int*>(smem);
+  float* Ys = smem + 4;
+  float* Xs = Ys + 32 * Sh::LDY;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+
+  f32x16 acc[Sh::RB][Sh::CB];
+#pragma unroll
+  for (int a = 0; a < Sh::RB; ++a)
+#pragma unroll
+    for (int b = 0; b < Sh::CB; ++b) acc[a][b] = zero16();
+
+  constexpr int Y4 = NN / 4, X4 = KK / 4;
+  for (;;) {
+    __syncthreads();                                   // previous tile fully consumed
+    if (tid == 0) s_next[0] = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    const int tile = s_next[0];
+    if (tile >= ntiles) break;
+    for (int idx = tid; idx < 32 * Y4; idx += 256)
+      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * Sh::LDY + 4 * (idx % Y4)]) = yl.load4(tile, idx / Y4, idx % Y4);
+    for (int idx = tid; idx < 32 * X4; idx += 256)
+      *reinterpret_cast<float4*>(&Xs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = xl.load4(tile, idx / X4, idx % X4);
+    __syncthreads();
+    // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;
+      const float* xrow = Xs + (2 * s + hh) * Sh::LDX + c;
+      float a[Sh::RB], b[Sh::CB];
+#pragma unroll
+      for (int i = 0; i < Sh::RB; ++i) a[i] = yrow[(w + 4 * i) * 32];
+#pragma unroll
+      for (int j = 0; j < Sh::CB; ++j) b[j] = xrow[j * 32];
+#pragma unroll
+      for (int i = 0; i < Sh::RB; ++i)
+#pragma unroll
+        for (int j = 0; j < Sh::CB; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+    }
+  }
+  float* out = slab + (size_t)blockIdx.x * (NN * KK);
+#pragma unroll
+  for (int i = 0; i < Sh::RB; ++i)
+#pragma unroll
+    for (int j = 0; j < Sh::CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        out[(size_t)((w + 4 * i) * 32 + ROW32(r, hh)) * KK + j * 32 + c] = acc[i][j][r];
+}
+
+// column sums over the rows of Y[M][ld] (columns [col0, col0+C)): slab[blockIdx.x][C]
+template <int C>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int64_t M, int ld, int col0,
+                                                      float* __restrict__ slab) {
+  constexpr int C4 = C / 4, RPB = (256 / C4) > 0 ? (256 / C4) : 1, ACTIVE = C4 * RPB;
+  static_assert(C4 <= 256, "colsum width");
+  __shared__ float4 red[256];
+  const int tid = threadIdx.x;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < ACTIVE) {
+    const int c4 = tid % C4;
+    for (int64_t r = (int64_t)blockIdx.x * RPB + tid / C4; r < M; r += (int64_t)gridDim.x * RPB) {
+      const float4 v = *reinterpret_cast<const float4*>(Y + r * ld + col0 + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (tid < C4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = tid; k < ACTIVE; k += C4) { const float4 u = red[k]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    *reinterpret_cast<float4*>(slab + (size_t)blockIdx.x * C + 4 * tid) = a;
+  }
+}
+
+// out[i] (+)= sum_s slab[s][i], s in fixed order; scale applied to the sum
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t count,
+                                                           float* __restrict__ out, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += slab[(size_t)k * count + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTM backward through time (mirror image of lstm_recurrence_kernel)
+// ------------------------------------------------------------------------------------------------
+// One workgroup = one direction x 32 sequences, all steps, walked against the forward order.  Per step:
+//   dh = upstream[t] + recurrent;  do = dh*tanh(c);  dc += dh*o*(1-tanh(c)^2);  di = dc*g;  dg = dc*i;  df = dc*c_prev;
+//   dP = (di*i(1-i), df*f(1-f), dg*(1-g^2), do*o(1-o))   [lane-local: same fragment slots as the forward]
+//   dP -> HBM (token-major, feeds the W_ih/W_hh/bias gradient GEMMs and the dy1 data gradient) and -> LDS;
+//   recurrent dh_{prev} = dP[32 x 512] * W_hh[512 x 128]   (256 MFMA per wave, W_hh^T resident in registers)
+constexpr int BPTT_LDP = 512 + 4;
+constexpr size_t BPTT_LDS_BYTES = sizeof(float) * 2 * 32 * BPTT_LDP;
+
+__global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict__ tape_gates,
+                                                         const float* __restrict__ tape_c,
+                                                         const float* __restrict__ whh_f, const float* __restrict__ whh_b,
+                                                         const float* __restrict__ dh_up, int ldh,
+                                                         float* __restrict__ dg_out, int ldg, int dump_row, SeqGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* DPs = smem;   // [2][32][BPTT_LDP]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int st = blockIdx.x, d = blockIdx.y;
+  const float* whh = d ? whh_b : whh_f;
+
+  // B operand of dh_prev = dP W_hh:  B[k = gate column][j = hidden unit 32w + c] = W_hh[k][32w + c]
+  float wf[256];
+#pragma unroll
+  for (int m = 0; m < 64; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[4 * m + t] = whh[(int64_t)(8 * m + 4 * hh + t) * LSTM_H + 32 * w + c];
+
+  const int tstride = seq_token_stride(g);
+  // processing order: against the forward order of this direction
+  const int t_first = d ? 0 : g.len - 1, tdir = d ? 1 : -1;
+  unsigned hidx[16], gidx[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = st * 32 + ROW32(r, hh);
+    const unsigned tokb = (q < g.nseq ? (unsigned)seq_token_base(g, q) : (unsigned)dump_row) + (unsigned)(t_first * tstride);
+    hidx[r] = tokb * (unsigned)ldh + (unsigned)(d * LSTM_H + 32 * w + c);
+    gidx[r] = tokb * (unsigned)ldg + (unsigned)(d * 512 + 32 * w + c);
+  }
+  const unsigned hstep = (unsigned)(tdir * tstride * ldh), gstep = (unsigned)(tdir * tstride * ldg);
+  const bool row_ok_any = true;
+  (void)row_ok_any;
+
+  f32x16 dh_rec = zero16(), dc_rec = zero16();
+  for (int step = 0; step < g.len; ++step) {
+    const int t = t_first + tdir * step;
+    const int t_prev = t - (d ? -1 : 1);                 // forward-order predecessor of t (d=0: t-1, d=1: t+1)
+    const bool has_prev = t_prev >= 0 && t_prev < g.len;
+    float* dp = DPs + (step & 1) * 32 * BPTT_LDP;
+    const float* tg = tape_gates + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)w * 1024 + lane * 4;
+    const float* tc = tape_c + pre_tile_offset(d, st, t, g.nst, g.len) / 4 + (int64_t)w * 1024 + lane * 4;
+    const float* tcp = tape_c + pre_tile_offset(d, st, has_prev ? t_prev : t, g.nst, g.len) / 4 + (int64_t)w * 1024 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 i4 = *reinterpret_cast<const float4*>(tg + 0 * 4096 + q * 256);
+      const float4 f4 = *reinterpret_cast<const float4*>(tg + 1 * 4096 + q * 256);
+      const float4 g4 = *reinterpret_cast<const float4*>(tg + 2 * 4096 + q * 256);
+      const float4 o4 = *reinterpret_cast<const float4*>(tg + 3 * 4096 + q * 256);
+      const float4 c4 = *reinterpret_cast<const float4*>(tc + q * 256);
+      float4 p4 = *reinterpret_cast<const float4*>(tcp + q * 256);
+      if (!has_prev) p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float iv[4] = {i4.x, i4.y, i4.z, i4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+      const float ov[4] = {o4.x, o4.y, o4.z, o4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        const float dh = dh_up[hidx[r]] + dh_rec[r];
+        const float tc_ = fast_tanh(cv[e]);
+        const float dc = dc_rec[r] + dh * ov[e] * (1.f - tc_ * tc_);
+        const float dpo = dh * tc_ * ov[e] * (1.f - ov[e]);
+        const float dpi = dc * gv[e] * iv[e] * (1.f - iv[e]);
+        const float dpf = dc * pv[e] * fv[e] * (1.f - fv[e]);
+        const float dpg = dc * iv[e] * (1.f - gv[e] * gv[e]);
+        dc_rec[r] = dc * fv[e];
+        const int row = ROW32(r, hh);
+        float* lp = dp + row * BPTT_LDP + 32 * w + c;
+        lp[0] = dpi; lp[128] = dpf; lp[256] = dpg; lp[384] = dpo;
+        float* gp = dg_out + gidx[r];
+        gp[0] = dpi; gp[128] = dpf; gp[256] = dpg; gp[384] = dpo;
+        hidx[r] += hstep;
+        gidx[r] += gstep;
+      }
+    }
+    __syncthreads();
+    // dh_rec = dP W_hh  (rows = sequences, K = 512 gate columns, this wave's 32 hidden units)
+    f32x16 acc = zero16();
+    const float* arow = dp + c * BPTT_LDP + 4 * hh;
+#pragma unroll
+    for (int m0 = 0; m0 < 64; m0 += 16) {
+      float4 afr[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 8 * (m0 + m));
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        acc = mfma32(afr[m].x, wf[4 * (m0 + m) + 0], acc);
+        acc = mfma32(afr[m].y, wf[4 * (m0 + m) + 1], acc);
+        acc = mfma32(afr[m].z, wf[4 * (m0 + m) + 2], acc);
+        acc = mfma32(afr[m].w, wf[4 * (m0 + m) + 3], acc);
+      }
+    }
+    dh_rec = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention backward (per sequence and head, everything on chip: len <= 256)
+// ------------------------------------------------------------------------------------------------
+//   P = softmax(scale * Q K^T);  O = P V  (forward, attention.h).  Given dO:
+//     delta[q] = <dO[q], O[q]>;  dP = dO V^T;  dS = P * (dP - delta);  dQ = scale dS K;  dK = scale dS^T Q;  dV = P^T dO
+// Phase A (wave = query block, score tiles transposed exactly as in the forward): softmax statistics, dQ.
+// Phase B (wave = key block): recompute the score tiles non-transposed (keys on lanes) so that the reductions over
+// queries (dK, dV) run over MFMA k-slots; per-query m, 1/l and delta come from phase A through LDS.
+template <int DH>
+struct AttnBwdShape {
+  static constexpr int LD = DH + 4;
+  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (4 * LD + 3)); }
+};
+
+template <int DH, int NKB>
+__global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ att,
+                                                                  const float* __restrict__ datt,
+                                                                  float* __restrict__ dqkv, int N, SeqGeom g,
+                                                                  float scale) {
+  using Sh = AttnBwdShape<DH>;
+  constexpr int LD = Sh::LD, ROWS = NKB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Ks = Qs + ROWS * LD;
+  float* Vs = Ks + ROWS * LD;
+  float* Ds = Vs + ROWS * LD;          // dO
+  float* Ms = Ds + ROWS * LD;          // row max (log2 domain)
+  float* Ls = Ms + ROWS;               // 1 / row sum
+  float* Es = Ls + ROWS;               // delta
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int seq = blockIdx.x, head = blockIdx.y;
+  const int len = g.len;
+  const int64_t tok0 = seq_token_base(g, seq);
+  const int tstride = seq_token_stride(g);
+  const int ld3 = 3 * N;
+  const float sl2e = scale * 1.4426950408889634f;
+
+  // ---- stage Q, K, V, dO rows of this (sequence, head); rows >= len are zero ------------------------
+  constexpr int R4 = DH / 4;
+  for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
+    const int p = idx / R4, f = idx % R4;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, d4 = q4;
+    if (p < len) {
+      const int64_t tok = tok0 + (int64_t)p * tstride;
+      const float* row = qkv + tok * ld3 + head * DH + 4 * f;
+      q4 = *reinterpret_cast<const float4*>(row);
+      k4 = *reinterpret_cast<const float4*>(row + N);
+      v4 = *reinterpret_cast<const float4*>(row + 2 * N);
+      d4 = *reinterpret_cast<const float4*>(datt + tok * N + head * DH + 4 * f);
+    }
+    *reinterpret_cast<float4*>(&Qs[p * LD + 4 * f]) = q4;
+    *reinterpret_cast<float4*>(&Ks[p * LD + 4 * f]) = k4;
+    *reinterpret_cast<float4*>(&Vs[p * LD + 4 * f]) = v4;
+    *reinterpret_cast<float4*>(&Ds[p * LD + 4 * f]) = d4;
+  }
+  __syncthreads();
+
+  // =================================== phase A: wave = query block ===================================
+  {
+    const int qb = wv;
+    const int p = qb * 32 + c;
+    float qf[DH / 2], df[DH / 2];
+    float dsum = 0.f;
+    {
+      const float* qrow = Qs + p * LD + 4 * hh;
+      const float* drow = Ds + p * LD + 4 * hh;
+      const int64_t tok = tok0 + (int64_t)(p < len ? p : 0) * tstride;
+      const float* orow = att + tok * N + head * DH + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * m);
+        const float4 d4 = *reinterpret_cast<const float4*>(drow + 8 * m);
+        float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * m);
+        if (p >= len) o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        qf[4 * m + 0] = q4.x * sl2e; qf[4 * m + 1] = q4.y * sl2e; qf[4 * m + 2] = q4.z * sl2e; qf[4 * m + 3] = q4.w * sl2e;
+        df[4 * m + 0] = d4.x; df[4 * m + 1] = d4.y; df[4 * m + 2] = d4.z; df[4 * m + 3] = d4.w;
+        dsum += d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
+      }
+    }
+    const float delta = dsum + __shfl_xor(dsum, 32);
+    f32x16 s[NKB];
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb) {
+      s[rb] = zero16();
+      const float* krow = Ks + (rb * 32 + c) * LD + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        const float4 k = *reinterpret_cast<const float4*>(krow + 8 * m);
+        s[rb] = mfma32(k.x, qf[4 * m + 0], s[rb]);
+        s[rb] = mfma32(k.y, qf[4 * m + 1], s[rb]);
+        s[rb] = mfma32(k.z, qf[4 * m + 2], s[rb]);
+        s[rb] = mfma32(k.w, qf[4 * m + 3], s[rb]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((NKB - 1) * 32 + ROW32(r, hh) >= len) s[NKB - 1][r] = -1e30f;
+    float mx = -1e30f;
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[rb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = fast_exp2(s[rb][r] - mx);
+        s[rb][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (hh == 0) {
+      Ms[p] = mx;
+      Ls[p] = inv;
+      Es[p] = delta;
+    }
+    // dS^T tile by tile, then dQ = scale * dS K
+    f32x16 dq = zero16();
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb) {
+      f32x16 dp = zero16();
+      const float* vrow = Vs + (rb * 32 + c) * LD + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(vrow + 8 * m);
+        dp = mfma32(v.x, df[4 * m + 0], dp);
+        dp = mfma32(v.y, df[4 * m + 1], dp);
+        dp = mfma32(v.z, df[4 * m + 2], dp);
+        dp = mfma32(v.w, df[4 * m + 3], dp);
+      }
+      float kk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float kval = Ks[(rb * 32 + ROW32(r, hh)) * LD + (c < DH ? c : 0)];
+        kk[r] = c < DH ? kval : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ds = s[rb][r] * inv * (dp[r] - delta);
+        dq = mfma32(ds, kk[r], dq);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pq = qb * 32 + ROW32(r, hh);
+      if (pq < len && c < DH) dqkv[(tok0 + (int64_t)pq * tstride) * ld3 + head * DH + c] = dq[r] * scale;
+    }
+  }
+  __syncthreads();
+
+  // =================================== phase B: wave = key block =====================================
+  {
+    const int kb = wv;
+    const int key = kb * 32 + c;
+    const bool key_ok = key < len;
+    float kf[DH / 2], vf[DH / 2];
+    {
+      const float* krow = Ks + key * LD + 4 * hh;
+      const float* vrow = Vs + key * LD + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * m);
+        const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * m);
+        kf[4 * m + 0] = k4.x; kf[4 * m + 1] = k4.y; kf[4 * m + 2] = k4.z; kf[4 * m + 3] = k4.w;
+        vf[4 * m + 0] = v4.x; vf[4 * m + 1] = v4.y; vf[4 * m + 2] = v4.z; vf[4 * m + 3] = v4.w;
+      }
+    }
+    f32x16 dk = zero16(), dv = zero16();
+#pragma unroll 1
+    for (int qb = 0; qb < NKB; ++qb) {
+      f32x16 s2 = zero16(), dp2 = zero16();
+      const float* qrow = Qs + (qb * 32 + c) * LD + 4 * hh;
+      const float* drow = Ds + (qb * 32 + c) * LD + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * m);
+        const float4 d4 = *reinterpret_cast<const float4*>(drow + 8 * m);
+        s2 = mfma32(q4.x, kf[4 * m + 0], s2);
+        s2 = mfma32(q4.y, kf[4 * m + 1], s2);
+        s2 = mfma32(q4.z, kf[4 * m + 2], s2);
+        s2 = mfma32(q4.w, kf[4 * m + 3], s2);
+        dp2 = mfma32(d4.x, vf[4 * m + 0], dp2);
+        dp2 = mfma32(d4.y, vf[4 * m + 1], dp2);
+        dp2 = mfma32(d4.z, vf[4 * m + 2], dp2);
+        dp2 = mfma32(d4.w, vf[4 * m + 3], dp2);
+      }
+      float qq[16], dd[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qrow_i = qb * 32 + ROW32(r, hh);
+        const float pm = Ms[qrow_i], pl = Ls[qrow_i], pe = Es[qrow_i];
+        const float p2 = key_ok ? fast_exp2(s2[r] * sl2e - pm) * pl : 0.f;
+        s2[r] = p2;                          // P
+        dp2[r] = p2 * (dp2[r] - pe);         // dS
+        const float qv = Qs[qrow_i * LD + (c < DH ? c : 0)], dv_ = Ds[qrow_i * LD + (c < DH ? c : 0)];
+        qq[r] = c < DH ? qv : 0.f;
+        dd[r] = c < DH ? dv_ : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dv = mfma32(s2[r], dd[r], dv);
+        dk = mfma32(dp2[r], qq[r], dk);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pk = kb * 32 + ROW32(r, hh);
+      if (pk < len && c < DH) {
+        float* row = dqkv + (tok0 + (int64_t)pk * tstride) * ld3 + head * DH + c;
+        row[N] = dk[r] * scale;
+        row[2 * N] = dv[r];
+      }
+    }
+  }
+}

@@ -16,6 +16,7 @@
 #include "headtail.h"
 #include "lstm.h"
 #include "sisnr.h"
+#include "backward.h"
 
 namespace {
 
@@ -104,6 +105,7 @@ struct dptnav_ctx {
   std::vector<std::string> names;
   std::vector<int64_t> numel;
   std::vector<const float*> ptr;
+  std::vector<float*> gptr;   // parameter-gradient destinations (dptnav_bind_grads), same slots as ptr
   bool bound = false;
   std::string err;
   int stride;
@@ -339,12 +341,12 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
 // The engine is persistent (grid-stride over tiles, weights loaded once per workgroup), so the grid is
 // sized to what is co-resident: CUs x blocks/CU from the occupancy query, queried once per instantiation.
-template <int KIN, int NT, int WR, int WC, class AL, class EP>
+template <int KIN, int NT, int WR, int WC, bool WT = false, class AL, class EP>
 int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float* W, int64_t ntiles, int colgroups,
-                const AL& al, const EP& ep, const float* Walt = nullptr) {
+                const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr) {
   hipStream_t st = run.st;
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
-  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP>;
+  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
   static int resident = 0;  // per instantiation
   if (resident == 0) {
@@ -357,18 +359,32 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
   int gx = resident / colgroups;
   if (gx < 1) gx = 1;
   ProfScope ps(c, cat, st);
-  hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, KIN, (int)ntiles,
+  if (grid_used) *grid_used = cap_grid(ntiles, gx);
+  hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, ldw, (int)ntiles,
                      run.take_queue(colgroups), al, ep);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
 
+// Where one path keeps its intermediates: the shared workspace slice (inference) or a per-path tape (training, where
+// the backward needs them: qkv, att, y1, raw h, post-activation gates and cell states).
+struct PathBufs {
+  float *qkv, *att, *y1, *pre, *hc, *gates, *cst;
+  bool train;
+};
+inline PathBufs inference_bufs(const Run& run) {
+  return PathBufs{run.ws + run.pl.qkv, run.ws + run.pl.att, run.ws + run.pl.y1, run.ws + run.pl.pre,
+                  run.ws + run.pl.hc, nullptr, nullptr, false};
+}
+
 // ---- one TransformerDPRNN (dptn.py:36-52) ---------------------------------------------------------
 template <int N>
-int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S) {
+int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
+             const PathBufs* bufs = nullptr) {
   float* ws = run.ws;
   const Plan& pl = run.pl;
   hipStream_t st = run.st;
+  const PathBufs pb = bufs ? *bufs : inference_bufs(run);
   constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4, DH = N / 4;
   constexpr int BM = 32 * WR;
   const dptnav_config& g = c->cfg;
@@ -376,7 +392,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const int K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K;
   const SeqGeom geom = make_geom(path, B, S, K);
-  float *qkv = ws + pl.qkv, *att = ws + pl.att, *y1 = ws + pl.y1, *pre = ws + pl.pre, *hc = ws + pl.hc;
+  float *qkv = pb.qkv, *att = pb.att, *y1 = pb.y1, *pre = pb.pre, *hc = pb.hc;
   const int64_t ntiles = (M + BM - 1) / BM;
   const bool dptn = g.arch == 0;
   const float* lstm_in = dptn ? y1 : x_in;   // DPRNN feeds the chunk tokens straight into the LSTM (dprnn.py:37-40)
@@ -406,7 +422,8 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
   {
-    auto kern = c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>;
+    auto kern = pb.train ? lstm_recurrence_kernel<false, true>
+                         : (c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>);
     if (int rc = set_lds(c, kern, LSTM_LDS_BYTES, "lstm")) return rc;
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
@@ -414,7 +431,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                       w.ndir * LSTM_H, (int)M, geom, stamps, c->cfg.arch == 0 ? 1 : 0);
+                       w.ndir * LSTM_H, (int)M, geom, stamps, (c->cfg.arch == 0 && !pb.train) ? 1 : 0, pb.gates, pb.cst);
     LAUNCH_CHECK(c, "lstm");
   }
   if (run.lstm_record && hipEventRecord(run.lstm_record, st) != hipSuccess)
@@ -434,11 +451,12 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
   {
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
+    // (training keeps the raw h on the tape and applies ffn[0] = ReLU while loading)
     if (w.ndir == 2) {
-      ALoadDense al{hc, M, 2 * LSTM_H, BM};
+      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM, pb.train};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else {
-      ALoadDense al{hc, M, LSTM_H, BM};
+      ALoadCols al{hc, M, LSTM_H, 0, BM, pb.train};
       if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     }
   }
@@ -510,6 +528,264 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
                        T, (int)pl.L, g.kernel_size_enc, c->stride, pad_left);
     LAUNCH_CHECK(c, "decoder gather");
   }
+  return DPTNAV_OK;
+}
+
+// =================================================================================================
+// training step, path level (BASELINE config 4): forward with a tape, backward from the tape
+// =================================================================================================
+struct PathTape {  // offsets in floats inside one path's tape
+  size_t qkv, att, y1, hc, gates, cst, total;
+};
+struct BwdPlan {   // offsets in floats inside the backward workspace
+  size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, total;
+  int slab_wgs;
+};
+constexpr int BWD_SLAB_WGS = 256;       // workgroups of one wgrad / colsum launch (one partial slab each)
+constexpr int BWD_LNP_WGS = 2048;       // upper bound of GEMM-engine workgroups writing LayerNorm partials
+
+int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
+  const dptnav_config& g = c->cfg;
+  const int64_t N = g.num_features, H = g.hidden_dim, K = g.chunk_size;
+  const int64_t M = (int64_t)B * S * K;
+  const int64_t nst = std::max(((int64_t)B * S + 31) / 32 * K, ((int64_t)B * K + 31) / 32 * S);
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align64(n); return at; };
+  t->qkv = take((size_t)M * 3 * N);
+  t->att = take((size_t)M * N);
+  t->y1 = take((size_t)M * N);
+  t->hc = take((size_t)(M + S * K) * 2 * H);
+  t->gates = take((size_t)2 * nst * 512 * 32);
+  t->cst = take((size_t)2 * nst * 128 * 32);
+  t->total = o;
+  return DPTNAV_OK;
+}
+
+int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p) {
+  const dptnav_config& g = c->cfg;
+  const int64_t N = g.num_features, H = g.hidden_dim, K = g.chunk_size;
+  const int64_t M = (int64_t)B * S * K, MD = M + (int64_t)S * K;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align64(n); return at; };
+  p->queue = take(QUEUE_SLOTS);
+  p->dz = take((size_t)M * N);
+  p->dh = take((size_t)MD * 2 * H);
+  p->dg = take((size_t)MD * 2 * 4 * H);
+  p->dy1 = take((size_t)M * N);
+  p->datt = take((size_t)M * N);
+  p->dqkv = take((size_t)M * 3 * N);
+  p->slab = take((size_t)BWD_SLAB_WGS * 512 * 128);
+  p->lnp = take((size_t)BWD_LNP_WGS * 2 * N);
+  p->total = o;
+  p->slab_wgs = BWD_SLAB_WGS;
+  return DPTNAV_OK;
+}
+
+struct BwdRun {
+  float* ws;
+  BwdPlan pl;
+  hipStream_t st;
+  int slot;
+  unsigned* take_queue(int n) {
+    unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
+    slot += n;
+    return q;
+  }
+};
+
+// dW[NN][KK] = sum_tokens Y^T X  ->  grad (overwrite)
+template <int NN, int KK, class YL, class XL>
+int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XL& xl, float* grad) {
+  auto kern = wgrad_kernel<NN, KK, YL, XL>;
+  const size_t lds = WgradShape<NN, KK>::lds_bytes();
+  static bool ready = false;
+  if (!ready) {
+    if (int rc = set_lds(c, kern, lds, what)) return rc;
+    ready = true;
+  }
+  const int grid = cap_grid(ntiles, br.pl.slab_wgs);
+  float* slab = br.ws + br.pl.slab;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab);
+  LAUNCH_CHECK(c, what);
+  const int64_t count = (int64_t)NN * KK;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, br.st, slab, grid, count,
+                     grad, 0);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
+// grad[C] = column sums of Y[:, col0:col0+C]   (second destination optional: b_ih and b_hh share their gradient)
+template <int C>
+int launch_colsum(dptnav_ctx* c, BwdRun& br, const char* what, const float* Y, int64_t M, int ld, int col0, float* grad,
+                  float* grad2 = nullptr) {
+  const int grid = br.pl.slab_wgs;
+  float* slab = br.ws + br.pl.slab;
+  hipLaunchKernelGGL(colsum_kernel<C>, dim3(grid), dim3(256), 0, br.st, Y, M, ld, col0, slab);
+  LAUNCH_CHECK(c, what);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad, 0);
+  if (grad2) hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad2, 0);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
+template <int N>
+int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const float* x_in, const float* d_out,
+                      float* d_in, int B, int S, float* tape, const PathTape& tp) {
+  constexpr int GROUP = N / 4, DH = N / 4;
+  static_assert(N == 128, "the training step is built for num_features = 128 (BASELINE config 4)");
+  const dptnav_config& g = c->cfg;
+  const PathWeights& w = c->pw[2 * block + path];
+  const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
+  auto G = [&](const char* leaf) { return c->gptr[c->slot(pre + leaf)]; };
+  if (w.ndir != 2) return c->fail(DPTNAV_ERR_INVALID, "training step: unidirectional inter-chunk LSTM not supported yet");
+  const int K = g.chunk_size;
+  const int64_t M = (int64_t)B * S * K;
+  const SeqGeom geom = make_geom(path, B, S, K);
+  hipStream_t st = br.st;
+  float *qkv = tape + tp.qkv, *att = tape + tp.att, *y1 = tape + tp.y1, *hc = tape + tp.hc, *gates = tape + tp.gates,
+        *cst = tape + tp.cst;
+  float *DZ = br.ws + br.pl.dz, *DHb = br.ws + br.pl.dh, *DG = br.ws + br.pl.dg, *DY1 = br.ws + br.pl.dy1,
+        *DATT = br.ws + br.pl.datt, *DQKV = br.ws + br.pl.dqkv, *LNP = br.ws + br.pl.lnp;
+  const int64_t ntiles = (M + 31) / 32;
+  Run run;   // the GEMM engine takes its ticket counters from a Run: alias it onto the backward workspace
+  run.ws = br.ws;
+  run.pl = Plan{};
+  run.pl.queue = br.pl.queue;
+  run.st = st;
+  run.slot = br.slot;
+  int grid = 0;
+
+  // 1. recompute z2 = relu(h) W_f^T + b_f + y1 and push d_out through LayerNorm 2
+  {
+    ALoadCols al{hc, M, 2 * LSTM_H, 0, 32, true};
+    EpiLNBackward<GROUP, 0> ep{DZ, w.ffn_b, y1, w.ln2_w, d_out, LNP, M, N, 32};
+    if (int rc = launch_gemm<2 * LSTM_H, 1, 1, 4>(c, run, CAT_FFN, "ffn recompute + ln2 bwd", w.ffn_w, ntiles, 1, al, ep,
+                                                 nullptr, 2 * LSTM_H, &grid))
+      return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
+    hipMemcpyAsync(G("ln2.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(G("ln2.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    LAUNCH_CHECK(c, "ln2 grads");
+  }
+  br.slot = run.slot;
+  // 2. ffn parameter gradients
+  if (int rc = launch_colsum<N>(c, br, "d ffn bias", DZ, M, N, 0, G("ffn.1.bias"))) return rc;
+  {
+    ALoadCols yl{DZ, M, N, 0, 32, false};
+    ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32, true};
+    if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
+  }
+  // 3. d h = (dz2 W_f) masked by the ReLU
+  run.slot = br.slot;
+  {
+    ALoadDense al{DZ, M, N, 32};
+    EpiAddMaskStore ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+    if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
+      return rc;
+  }
+  br.slot = run.slot;
+  // 4. LSTM backward through time
+  {
+    static bool ready = false;
+    if (!ready) {
+      if (int rc = set_lds(c, lstm_bptt_kernel, BPTT_LDS_BYTES, "lstm bptt")) return rc;
+      ready = true;
+    }
+    ProfScope ps(c, CAT_LSTM, st);
+    hipLaunchKernelGGL(lstm_bptt_kernel, dim3(geom.nst, 2), dim3(256), BPTT_LDS_BYTES, st, gates, cst, w.w_hh[0], w.w_hh[1],
+                       DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom);
+    LAUNCH_CHECK(c, "lstm bptt");
+  }
+  // 5. LSTM parameter gradients
+  for (int d = 0; d < 2; ++d) {
+    const char* sfx = d ? "_reverse" : "";
+    const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
+                      bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
+    if (int rc = launch_colsum<512>(c, br, "d lstm bias", DG, M, 2 * 512, d * 512, G(bih.c_str()), G(bhh.c_str()))) return rc;
+    ALoadDense xl{y1, M, N, 32};
+    ALoadSeqShift hl{hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom};
+    for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
+      ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32, false};
+      if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
+      if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
+    }
+  }
+  // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
+  run.slot = br.slot;
+  for (int d = 0; d < 2; ++d) {
+    ALoadCols al{DG, M, 2 * 512, d * 512, 32, false};
+    EpiAddMaskStore ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
+    if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
+      return rc;
+  }
+  // 7. recompute z1 = att W_o^T + b_o + x and push d y1 through LayerNorm 1
+  {
+    ALoadDense al{att, M, N, 32};
+    EpiLNBackward<GROUP, 0> ep{DZ, w.out_b, x_in, w.ln1_w, DY1, LNP, M, N, 32};
+    if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_OUTPROJ, "out-proj recompute + ln1 bwd", w.out_w, ntiles, 1, al, ep,
+                                        nullptr, N, &grid))
+      return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
+    hipMemcpyAsync(G("ln1.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(G("ln1.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    LAUNCH_CHECK(c, "ln1 grads");
+  }
+  br.slot = run.slot;
+  // 8. out-projection gradients and d att
+  if (int rc = launch_colsum<N>(c, br, "d out bias", DZ, M, N, 0, G("mha.out_proj.bias"))) return rc;
+  {
+    ALoadCols yl{DZ, M, N, 0, 32, false};
+    ALoadDense xl{att, M, N, 32};
+    if (int rc = launch_wgrad<N, N>(c, br, "d out weight", ntiles, yl, xl, G("mha.out_proj.weight"))) return rc;
+  }
+  run.slot = br.slot;
+  {
+    ALoadDense al{DZ, M, N, 32};
+    EpiAddMaskStore ep{DATT, nullptr, nullptr, M, N, 32, N};
+    if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+  }
+  br.slot = run.slot;
+  // 9. attention backward
+  {
+    const int nkb = (geom.len + 31) / 32;
+    const float scale = 1.0f / sqrtf((float)DH);
+    auto launch = [&](auto kern, int threads) -> int {
+      const size_t lds = AttnBwdShape<DH>::lds_bytes(nkb);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "attention bwd lds: %s", hipGetErrorString(e));
+      ProfScope ps(c, CAT_ATTN, st);
+      hipLaunchKernelGGL(kern, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, N, geom, scale);
+      return DPTNAV_OK;
+    };
+    int rc = DPTNAV_OK;
+    switch (nkb) {
+      case 1: rc = launch(attention_bwd_kernel<DH, 1>, 64); break;
+      case 2: rc = launch(attention_bwd_kernel<DH, 2>, 128); break;
+      case 3: rc = launch(attention_bwd_kernel<DH, 3>, 192); break;
+      case 4: rc = launch(attention_bwd_kernel<DH, 4>, 256); break;
+      case 5: rc = launch(attention_bwd_kernel<DH, 5>, 320); break;
+      case 6: rc = launch(attention_bwd_kernel<DH, 6>, 384); break;
+      case 7: rc = launch(attention_bwd_kernel<DH, 7>, 448); break;
+      case 8: rc = launch(attention_bwd_kernel<DH, 8>, 512); break;
+      default: return c->fail(DPTNAV_ERR_INVALID, "attention bwd: sequence length %d > 256", geom.len);
+    }
+    if (rc) return rc;
+    LAUNCH_CHECK(c, "attention bwd");
+  }
+  // 10. in-projection gradients and d x = dz1 (residual) + dqkv W_in
+  if (int rc = launch_colsum<3 * N>(c, br, "d in bias", DQKV, M, 3 * N, 0, G("mha.in_proj_bias"))) return rc;
+  {
+    ALoadCols yl{DQKV, M, 3 * N, 0, 32, false};
+    ALoadDense xl{x_in, M, N, 32};
+    if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight", ntiles, yl, xl, G("mha.in_proj_weight"))) return rc;
+  }
+  run.slot = br.slot;
+  {
+    ALoadDense al{DQKV, M, 3 * N, 32};
+    EpiAddMaskStore ep{d_in, DZ, nullptr, M, N, 32, N};
+    if (int rc = launch_gemm<3 * N, 1, 1, 4, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+  }
+  br.slot = run.slot;
   return DPTNAV_OK;
 }
 
@@ -797,6 +1073,69 @@ int dptnav_sisnr_pairs(dptnav_handle h, const float* s1_pred, const float* s2_pr
                      out);
   LAUNCH_CHECK(h, "sisnr_pairs");
   return DPTNAV_OK;
+}
+
+// ---- training step, path level ------------------------------------------------------------------------
+int dptnav_bind_grads(dptnav_handle h, float* const* dev_ptrs, int n) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!dev_ptrs || n != (int)h->names.size())
+    return h->fail(DPTNAV_ERR_WEIGHTS, "expected %zu gradient pointers, got %d", h->names.size(), n);
+  for (int i = 0; i < n; ++i)
+    if (dev_ptrs[i] == nullptr || ((uintptr_t)dev_ptrs[i] & 15) != 0)
+      return h->fail(DPTNAV_ERR_WEIGHTS, "gradient pointer for %s is null or not 16-byte aligned", h->names[i].c_str());
+  h->gptr.assign(dev_ptrs, dev_ptrs + n);
+  return DPTNAV_OK;
+}
+size_t dptnav_train_path_tape_bytes(dptnav_handle h, int B, int S) {
+  if (!h) return 0;
+  PathTape t;
+  make_path_tape(h, B, S, &t);
+  return t.total * sizeof(float);
+}
+size_t dptnav_train_bwd_workspace_bytes(dptnav_handle h, int B, int S) {
+  if (!h) return 0;
+  BwdPlan p;
+  make_bwd_plan(h, B, S, &p);
+  return p.total * sizeof(float);
+}
+int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S,
+                              void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
+    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !x_out || !tape)
+    return h->fail(DPTNAV_ERR_INVALID, "train_path_forward: bad argument");
+  PathTape tp;
+  make_path_tape(h, B, S, &tp);
+  if (tape_bytes < tp.total * sizeof(float)) return h->fail(DPTNAV_ERR_WORKSPACE, "tape too small");
+  const int64_t L = (int64_t)(S - 1) * h->cfg.step_size + h->cfg.chunk_size;
+  const int64_t T = (L - 1) * h->stride + h->cfg.kernel_size_enc;
+  Plan pl;
+  if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
+  Run run;
+  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  float* tb = (float*)tape;
+  PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true};
+  return run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb);
+}
+int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
+                               int B, int S, void* tape, size_t tape_bytes, void* bws, size_t bws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
+    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
+  if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !d_out || !d_in || !tape || !bws)
+    return h->fail(DPTNAV_ERR_INVALID, "train_path_backward: bad argument");
+  PathTape tp;
+  make_path_tape(h, B, S, &tp);
+  BwdPlan bp;
+  make_bwd_plan(h, B, S, &bp);
+  if (tape_bytes < tp.total * sizeof(float) || bws_bytes < bp.total * sizeof(float) || ((uintptr_t)bws & 255) != 0)
+    return h->fail(DPTNAV_ERR_WORKSPACE, "tape or backward workspace too small / misaligned");
+  BwdRun br{(float*)bws, bp, (hipStream_t)stream, 0};
+  if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), br.st) != hipSuccess)
+    return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+  return run_path_backward<128>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp);
 }
 
 // ---- tuning / diagnostic knobs ----------------------------------------------------------------------

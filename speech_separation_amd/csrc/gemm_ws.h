@@ -31,7 +31,9 @@ struct GemmShape {
   }
 };
 
-template <int KIN, int NT, int WR, int WC, class ALoad, class Epi>
+// WT = true: the B fragments are fetched from W TRANSPOSED, i.e. out[m][j] = sum_k A[m][k] * W[k][j] with W stored
+// [KIN][ldw] -- the data-gradient form of a layer whose forward weight is W[NOUT_fwd = KIN][KIN_fwd = out cols].
+template <int KIN, int NT, int WR, int WC, class ALoad, class Epi, bool WT = false>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ W,
                                                        const float* __restrict__ Walt, int ldw, int ntiles,
                                                        unsigned* __restrict__ tile_queue, ALoad aload, Epi epi) {
@@ -55,14 +57,22 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int j = jbase + (wc * NT + nt) * 32 + c;
-    const float* wrow = Wsel + (int64_t)j * ldw + 4 * hh;
+    if constexpr (!WT) {
+      const float* wrow = Wsel + (int64_t)j * ldw + 4 * hh;
 #pragma unroll
-    for (int m = 0; m < KIN / 8; ++m) {
-      const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * m);
-      wf[nt][4 * m + 0] = v.x;
-      wf[nt][4 * m + 1] = v.y;
-      wf[nt][4 * m + 2] = v.z;
-      wf[nt][4 * m + 3] = v.w;
+      for (int m = 0; m < KIN / 8; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * m);
+        wf[nt][4 * m + 0] = v.x;
+        wf[nt][4 * m + 1] = v.y;
+        wf[nt][4 * m + 2] = v.z;
+        wf[nt][4 * m + 3] = v.w;
+      }
+    } else {
+      const float* wcol = Wsel + j + (int64_t)(4 * hh) * ldw;   // element (k, j) at W[k*ldw + j]
+#pragma unroll
+      for (int m = 0; m < KIN / 8; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[nt][4 * m + t] = wcol[(int64_t)(8 * m + t) * ldw];
     }
   }
 
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     tile = next;
     buf ^= 1;
   }
+  if constexpr (Epi::HAS_FINISH) epi.finish(smem, tid);   // e.g. per-workgroup partial sums of parameter gradients
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -226,6 +237,7 @@ struct ALoadSeqTile {
 // out[row][colgroup*WGCOLS + 4*c4 ..] = v + bias
 struct EpiBiasStore {
   static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
   float* out;
   const float* bias;
   int64_t M;
@@ -247,6 +259,7 @@ struct EpiBiasStore {
 template <int GROUP>
 struct EpiBiasResLN {
   static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
   float* out;
   const float* bias;
   const float* res;    // [M][ld]
@@ -285,6 +298,7 @@ struct EpiBiasResLN {
 template <int GROUP>
 struct EpiBiasLNRes {
   static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
   float* out;
   const float* bias;
   const float* res;    // [M][ld]
@@ -321,6 +335,7 @@ struct EpiBiasLNRes {
 // LSTM pre-activations straight from the accumulators into the fragment layout (common.h)
 struct EpiLstmPre {
   static constexpr bool DIRECT = true;
+  static constexpr bool HAS_FINISH = false;
   float* pre;
   const float* b_ih[2];
   const float* b_hh[2];
@@ -342,3 +357,119 @@ struct EpiLstmPre {
   }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// training-step hooks (backward pass)
+// ------------------------------------------------------------------------------------------------
+// dense rows with ReLU applied on the fly (training keeps the raw LSTM output h; ffn = ReLU -> Linear, dptn.py:30-33)
+struct ALoadDenseReLU {
+  const float* A;
+  int64_t M;
+  int lda;
+  int bm;
+  DEV float4 load4(int tile, int row, int k4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(A + r * lda + 4 * k4);
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+  }
+};
+
+// out[row][col] = (v + addend[row][col]) * (gate[row][col] > 0 ? 1 : 0); addend / gate may be null
+struct EpiAddMaskStore {
+  static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
+  float* out;
+  const float* addend;   // [M][ldo] or null
+  const float* gate;     // [M][ldo] or null: ReLU mask source (forward activation)
+  int64_t M;
+  int ldo;
+  int bm;
+  int wgcols;
+  DEV float4 prefetch(int tile, int row, int c4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (addend == nullptr || r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(addend + r * ldo + 4 * c4);   // (single column group only)
+  }
+  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 a) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    if (r >= M) return;
+    const int col = colgroup * wgcols + 4 * c4;
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    if (gate != nullptr) {
+      const float4 g = *reinterpret_cast<const float4*>(gate + r * ldo + col);
+      v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + r * ldo + col) = v;
+  }
+};
+
+// Recompute z = v + bias + res (the pre-LayerNorm activation) and apply the LayerNorm backward to the incoming
+// gradient:  dz = rstd * (g - mean(g) - zn * mean(g * zn)),  g = dout * gamma,  zn = (z - mu) * rstd;
+// d gamma += dout * zn, d beta += dout (per-thread column sums, reduced per workgroup into `partials`).
+// MODE 0: LayerNorm(v + bias + res)  (DPTN: dptn.py:46-47,50-51);  MODE 1: LayerNorm(v + bias) + res  (DPRNN).
+template <int GROUP, int MODE>
+struct EpiLNBackward {
+  static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = true;
+  float* dz;             // [M][ld] gradient w.r.t. the pre-norm activation
+  const float* bias;
+  const float* res;      // [M][ld]
+  const float* gamma;
+  const float* dout;     // [M][ld]
+  float* partials;       // [gridDim.x][2 * 4*GROUP]  (d gamma | d beta)
+  int64_t M;
+  int ld;
+  int bm;
+  float4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};   // this thread's column sums (its c4 is fixed)
+  DEV float4 prefetch(int tile, int row, int c4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) {
+    const int64_t r = (int64_t)tile * bm + row;
+    const bool ok = r < M;
+    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (MODE == 0) { v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+    const float mu = group_sum<GROUP>((v.x + v.y) + (v.z + v.w)) * (1.0f / (4 * GROUP));
+    const float dx = v.x - mu, dy = v.y - mu, dzz = v.z - mu, dw = v.w - mu;
+    const float var = group_sum<GROUP>((dx * dx + dy * dy) + (dzz * dzz + dw * dw)) * (1.0f / (4 * GROUP));
+    const float rstd = rsqrtf(var + 1e-5f);
+    const float4 zn = make_float4(dx * rstd, dy * rstd, dzz * rstd, dw * rstd);
+    float4 d = ok ? *reinterpret_cast<const float4*>(dout + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sg.x += d.x * zn.x; sg.y += d.y * zn.y; sg.z += d.z * zn.z; sg.w += d.w * zn.w;
+    sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+    const float4 g = make_float4(d.x * ga.x, d.y * ga.y, d.z * ga.z, d.w * ga.w);
+    const float m1 = group_sum<GROUP>((g.x + g.y) + (g.z + g.w)) * (1.0f / (4 * GROUP));
+    const float m2 = group_sum<GROUP>((g.x * zn.x + g.y * zn.y) + (g.z * zn.z + g.w * zn.w)) * (1.0f / (4 * GROUP));
+    if (!ok) return;
+    float4 o;
+    o.x = rstd * (g.x - m1 - zn.x * m2);
+    o.y = rstd * (g.y - m1 - zn.y * m2);
+    o.z = rstd * (g.z - m1 - zn.z * m2);
+    o.w = rstd * (g.w - m1 - zn.w * m2);
+    *reinterpret_cast<float4*>(dz + r * ld + 4 * c4) = o;
+  }
+  // 256 threads = (256/GROUP) row lanes x GROUP column lanes: reduce the row lanes through LDS
+  DEV void finish(float* smem, int tid) {
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);          // [2][256]
+    red[tid] = sg;
+    red[256 + tid] = sb;
+    __syncthreads();
+    if (tid < GROUP) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      for (int k = tid; k < 256; k += GROUP) {
+        const float4 u = red[k], w = red[256 + k];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+      }
+      float* p = partials + (size_t)blockIdx.x * (8 * GROUP);
+      *reinterpret_cast<float4*>(p + 4 * tid) = a;
+      *reinterpret_cast<float4*>(p + 4 * GROUP + 4 * tid) = b;
+    }
+  }
+};

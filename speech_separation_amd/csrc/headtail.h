@@ -136,6 +136,7 @@ struct ALoadOla {
 template <int GROUP>
 struct EpiSkipDecoderTaps {
   static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
   float* D;            // (2*B*L, 8) decoder tap products
   const float* bias;   // postprocessing bias
   const float* E;      // (B*L, N)

@@ -26,13 +26,18 @@ constexpr size_t LSTM_LDS_BYTES = sizeof(float) * (LSTM_HS_FLOATS + LSTM_PRE_FLO
 // hc has one extra "dump" row at index M (rows of padded sequences are written there, branch-free).
 // STAMP = true is a diagnostic build: per-wave s_memtime sums of the step's segments are written to `stamps`
 // ([workgroup][wave][4] cycles: acc-init, MFMA, cell, barrier); its run time is not representative.
-template <bool STAMP>
+// SAVE = true (training forward): the post-activation gates i,f,g,o and the cell state c_t of every step are kept for
+// the BPTT kernel, in the same accumulator-fragment order as the pre-activations:
+//   tape_gates[d][st][t][cb16][q4][hh2][c32][i4]   (64 KiB per tile and step)
+//   tape_c    [d][st][t][w4 ][q4][hh2][c32][i4]    (16 KiB per tile and step)
+template <bool STAMP, bool SAVE = false>
 __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __restrict__ pre,
                                                                const float* __restrict__ whh_f,
                                                                const float* __restrict__ whh_b,
                                                                float* __restrict__ hc, int ldh, int dump_row,
                                                                SeqGeom g, unsigned long long* __restrict__ stamps,
-                                                               int relu_out) {
+                                                               int relu_out, float* __restrict__ tape_gates = nullptr,
+                                                               float* __restrict__ tape_c = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                      // [2][32][LSTM_LDH]
   float* Ps = smem + LSTM_HS_FLOATS;     // [4 waves][16 pieces][64 lanes][4]
@@ -169,9 +174,23 @@ __global__ __launch_bounds__(256) void lstm_recurrence_kernel(const float* __res
       const float og = fast_sigmoid(acc[3][r]);
       const float cn = fmaf(fg, cst[r], ig * gg);
       cst[r] = cn;
+      if (SAVE) { acc[0][r] = ig; acc[1][r] = fg; acc[2][r] = gg; acc[3][r] = og; }
       const float hn = og * fast_tanh(cn);
       hnext[ROW32(r, hh) * LSTM_LDH + 32 * w + c] = hn;
       hout[r] = relu_out ? fmaxf(hn, 0.f) : hn;   // DPTN feeds ffn = ReLU -> Linear; DPRNN feeds fc directly
+    }
+    if (SAVE) {
+      float* tg = tape_gates + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)w * 1024 + lane * 4;
+      float* tc = tape_c + pre_tile_offset(d, st, t, g.nst, g.len) / 4 + (int64_t)w * 1024 + lane * 4;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(tg + gi * 4096 + q * 256) =
+              make_float4(acc[gi][4 * q], acc[gi][4 * q + 1], acc[gi][4 * q + 2], acc[gi][4 * q + 3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(tc + q * 256) = make_float4(cst[4 * q], cst[4 * q + 1], cst[4 * q + 2], cst[4 * q + 3]);
     }
     if (STAMP) c3 = __builtin_amdgcn_s_memtime();
     __syncthreads();

@@ -178,6 +178,46 @@ class DptnEngine:
             self._raise(rc, "dptnav_forward")
         return s1, s2
 
+    # ------------------------------------------------------------------ training step, path level
+    def bind_grads(self) -> Dict[str, torch.Tensor]:
+        """Allocate one gradient buffer per parameter slot (library WRITES them) and bind them; returns {key: tensor}."""
+        grads, ptrs = {}, (C.c_void_p * len(self.slots))()
+        for i, (key, shape) in enumerate(self.slots):
+            g = torch.zeros(shape, device=self.device)
+            grads[key] = g
+            ptrs[i] = g.data_ptr()
+        rc = self.lib.dptnav_bind_grads(self._h, ptrs, len(self.slots))
+        if rc:
+            self._raise(rc, "dptnav_bind_grads")
+        self._grads = grads
+        return grads
+
+    def train_path_forward(self, block: int, path: int, x: torch.Tensor):
+        B, S, K, N = x.shape
+        x = _check(x, "x", (B, S, self.cfg.chunk_size, self.cfg.num_features), self.device)
+        ws = self._workspace(B, self._path_T(S), 1)
+        tape = torch.empty(int(self.lib.dptnav_train_path_tape_bytes(self._h, B, S)), dtype=torch.uint8, device=self.device)
+        y = torch.empty_like(x)
+        rc = self.lib.dptnav_train_path_forward(self._h, block, path, x.data_ptr(), y.data_ptr(), B, S, tape.data_ptr(),
+                                                tape.numel(), ws.data_ptr(), ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_train_path_forward")
+        return y, tape
+
+    def train_path_backward(self, block: int, path: int, x: torch.Tensor, dy: torch.Tensor, tape: torch.Tensor):
+        B, S, K, N = x.shape
+        dy = _check(dy, "dy", tuple(x.shape), self.device)
+        need = int(self.lib.dptnav_train_bwd_workspace_bytes(self._h, B, S))
+        if getattr(self, "_bws", None) is None or self._bws.numel() < need:
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        dx = torch.empty_like(x)
+        rc = self.lib.dptnav_train_path_backward(self._h, block, path, x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, S,
+                                                 tape.data_ptr(), tape.numel(), self._bws.data_ptr(), self._bws.numel(),
+                                                 self._stream())
+        if rc:
+            self._raise(rc, "dptnav_train_path_backward")
+        return dx
+
     # ------------------------------------------------------------------ loss / metric statistics
     def sisnr_pairs(self, s1_pred, s2_pred, s1, s2, mix) -> torch.Tensor:
         """(B,6,2) device tensor: [metric dB, loss term] for the pairs (p1,s1) (p1,s2) (p2,s1) (p2,s2) (mix,s1) (mix,s2)."""

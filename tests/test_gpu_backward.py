@@ -1,0 +1,70 @@
+"""Training-step parity (GPU): the path-level backward of libdptnav against torch.autograd on the stock-PyTorch CPU
+composition (oracle/torch_stock.py) -- the same graph the reference's loss.backward() differentiates (dptn.py:36-52)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dptn_oracle as O
+from oracle.torch_stock import StockDPTN
+from speech_separation_amd.spec import DPTN_AV, DPTNConfig, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_path_backward_matches_autograd(dev, path):
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1, "dropout": 0.0})
+    sd = synthetic_state_dict(cfg, seed=4)
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(sd, dev))
+    grads = eng.bind_grads()
+    B, S, K, N = 2, 3, cfg.chunk_size, cfg.num_features
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, S, K, N)).astype(np.float32)
+    dy = rng.standard_normal((B, S, K, N)).astype(np.float32)
+
+    # ---- ours ----
+    xt = torch.from_numpy(x).to(dev)
+    y, tape = eng.train_path_forward(0, path, xt)
+    y_inf = eng.stage_path(0, path, xt)
+    assert O.agreement_db(y.cpu().numpy(), y_inf.cpu().numpy()) > 120          # training forward == inference forward
+    dx = eng.train_path_backward(0, path, xt, torch.from_numpy(dy).to(dev), tape)
+    torch.cuda.synchronize()
+
+    # ---- torch autograd on CPU (float64 for a tight reference) ----
+    ref = StockDPTN(cfg, sd)
+    name = "intra_chunk_block" if path == 0 else "inter_chunk_block"
+    pre = f"dprnn.model.0.{name}."
+    _, mha, rnn = ref.paths[path]
+    mha, rnn = mha.double().train(False), rnn.double()
+    params = {k: v.double().requires_grad_(True) for k, v in ref.sd.items() if k.startswith(pre)}
+    ref.sd.update(params)
+    for p in list(mha.parameters()) + list(rnn.parameters()):
+        p.requires_grad_(True)
+    xs = torch.from_numpy(x).double()
+    seqs = (xs.reshape(B * S, K, N) if path == 0 else xs.transpose(1, 2).reshape(B * K, S, N)).requires_grad_(True)
+    with torch.enable_grad():
+        out = ref._path.__wrapped__(ref, seqs, pre, mha, rnn) if hasattr(ref._path, "__wrapped__") else ref._path(seqs, pre, mha, rnn)
+        dys = torch.from_numpy(dy).double()
+        dseq = dys.reshape(B * S, K, N) if path == 0 else dys.transpose(1, 2).reshape(B * K, S, N)
+        out.backward(dseq)
+    want_dx = seqs.grad.reshape(B, S, K, N) if path == 0 else seqs.grad.reshape(B, K, S, N).transpose(1, 2)
+    assert O.agreement_db(dx.cpu().numpy(), want_dx.numpy()) > 80, "d x"
+
+    want = {"mha.in_proj_weight": mha.in_proj_weight.grad, "mha.in_proj_bias": mha.in_proj_bias.grad,
+            "mha.out_proj.weight": mha.out_proj.weight.grad, "mha.out_proj.bias": mha.out_proj.bias.grad}
+    for k, v in rnn.named_parameters():
+        want["rnn." + k] = v.grad
+    for leaf in ("ln1.weight", "ln1.bias", "ffn.1.weight", "ffn.1.bias", "ln2.weight", "ln2.bias"):
+        want[leaf] = params[pre + leaf].grad
+    for leaf, gref in want.items():
+        got = grads[pre + leaf].cpu().numpy()
+        assert got.shape == tuple(gref.shape), leaf
+        assert O.agreement_db(got, gref.numpy()) > 70, (leaf, O.agreement_db(got, gref.numpy()))
