@@ -152,6 +152,22 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
                                int B, int S, void* tape, size_t tape_bytes, void* bwd_workspace,
                                size_t bwd_workspace_bytes, void* stream);
 
+/* ---- training step, whole model ------------------------------------------------------------------------------
+ * dptnav_train_forward  = dptnav_forward that records the tape (single stream, no half-batch overlap);
+ * dptnav_train_backward = everything torch.autograd would do for the model part of loss.backward()
+ *   (src/trainer/trainer.py:47): given d loss / d s1_pred and d loss / d s2_pred it WRITES the gradient of every
+ *   parameter into the buffers bound with dptnav_bind_grads.  The loss itself (src/loss/ss_losses.py), gradient
+ *   clipping and the optimizer stay the reference's own PyTorch code (speech_separation_amd/model.py wraps these two
+ *   calls in a torch.autograd.Function).  Attention dropout must be 0. */
+size_t dptnav_train_tape_bytes(dptnav_handle h, int B, int64_t T, int Tv);
+size_t dptnav_train_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv);
+int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+                         float* s1_pred, float* s2_pred, void* tape, size_t tape_bytes, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, const float* e2, const float* d_s1_pred,
+                          const float* d_s2_pred, int B, int64_t T, int Tv, void* tape, size_t tape_bytes,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning / diagnostic knobs (never needed for correct results).  Keys:
  *   "overlap" (0/1, default 1): dptnav_forward runs the batch as two halves on two internal streams (forked from
  *                 and joined to the caller's stream by events) so that one half's GEMM/attention launches fill the

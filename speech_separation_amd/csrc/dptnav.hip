@@ -17,6 +17,7 @@
 #include "lstm.h"
 #include "sisnr.h"
 #include "backward.h"
+#include "backward_ends.h"
 
 namespace {
 
@@ -465,14 +466,14 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
 
 template <int N>
 int run_head(dptnav_ctx* c, Run& run, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
-             float* E, float* X) {
+             float* E, float* X, float* vidbuf = nullptr) {
   float* ws = run.ws;
   const Plan& pl = run.pl;
   hipStream_t st = run.st;
   const dptnav_config& g = c->cfg;
   const float* vid = nullptr;
   if (!g.audio_only) {
-    float* v = ws + pl.vid;
+    float* v = vidbuf ? vidbuf : ws + pl.vid;
     ProfScope ps(c, CAT_VIDEO, st);
     hipLaunchKernelGGL(video_linear_kernel, dim3(2 * B, g.hidden_video / 8), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
                        c->w("visual_compression.bias"), v, g.video_emb_size, Tv, g.hidden_video / 2);
@@ -490,14 +491,15 @@ int run_head(dptnav_ctx* c, Run& run, const float* mix, const float* e1, const f
 }
 
 template <int N>
-int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int64_t T, float* s1, float* s2) {
+int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int64_t T, float* s1, float* s2,
+             float* Zbuf = nullptr) {
   float* ws = run.ws;
   const Plan& pl = run.pl;
   hipStream_t st = run.st;
   constexpr int WR = N == 128 ? 1 : 2, WC = N == 128 ? 4 : 2, GROUP = N / 4;
   constexpr int BM = 32 * WR;
   const dptnav_config& g = c->cfg;
-  float *Z = ws + pl.qkv, *D = ws + pl.att;
+  float *Z = Zbuf ? Zbuf : ws + pl.qkv, *D = ws + pl.att;
   const int64_t M = pl.M;
   // T1: Z = PReLU(x) W_sep^T + b_sep                            (dptn_wav.py:26-29,47)
   {
@@ -538,7 +540,7 @@ struct PathTape {  // offsets in floats inside one path's tape
   size_t qkv, att, y1, hc, gates, cst, total;
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
-  size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, total;
+  size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
   int slab_wgs;
 };
 constexpr int BWD_SLAB_WGS = 256;       // workgroups of one wgrad / colsum launch (one partial slab each)
@@ -561,10 +563,11 @@ int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
   return DPTNAV_OK;
 }
 
-int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p) {
+int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv = 1) {
   const dptnav_config& g = c->cfg;
   const int64_t N = g.num_features, H = g.hidden_dim, K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K, MD = M + (int64_t)S * K;
+  if (L == 0) L = (int64_t)(S - 1) * g.step_size + K;
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align64(n); return at; };
   p->queue = take(QUEUE_SLOTS);
@@ -575,7 +578,14 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p) {
   p->datt = take((size_t)M * N);
   p->dqkv = take((size_t)M * 3 * N);
   p->slab = take((size_t)BWD_SLAB_WGS * 512 * 128);
-  p->lnp = take((size_t)BWD_LNP_WGS * 2 * N);
+  p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
+  p->dxa = take((size_t)M * N);                     // gradient ping-pong between paths
+  p->dxb = take((size_t)M * N);
+  p->dq = take((size_t)2 * B * L * N);
+  p->du = take((size_t)2 * B * L * N);
+  p->de = take((size_t)B * L * N);
+  p->dvi = take((size_t)B * L * N);
+  p->dv = take((size_t)B * (Tv > 0 ? Tv : 1) * N);
   p->total = o;
   p->slab_wgs = BWD_SLAB_WGS;
   return DPTNAV_OK;
@@ -786,6 +796,142 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<3 * N, 1, 1, 4, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles, 1, al, ep, nullptr, N)) return rc;
   }
   br.slot = run.slot;
+  return DPTNAV_OK;
+}
+
+// =================================================================================================
+// training step, whole model
+// =================================================================================================
+struct ModelTape {   // offsets in floats
+  size_t E, vid, Z, X0;            // X0: (2*num_blocks + 1) token buffers, M*N each
+  size_t paths;                    // 2*num_blocks path tapes
+  size_t path_stride, x_stride, total;
+  PathTape pt;
+};
+
+int make_model_tape(dptnav_ctx* c, int B, int64_t L, int S, int Tv, ModelTape* t) {
+  const dptnav_config& g = c->cfg;
+  const int64_t N = g.num_features, K = g.chunk_size, M = (int64_t)B * S * K;
+  make_path_tape(c, B, S, &t->pt);
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += align64(n); return at; };
+  t->E = take((size_t)B * L * N);
+  t->vid = take((size_t)B * (Tv > 0 ? Tv : 1) * N);
+  t->Z = take((size_t)M * 2 * N);
+  t->x_stride = align64((size_t)M * N);
+  t->X0 = take(t->x_stride * (2 * g.num_blocks + 1));
+  t->path_stride = align64(t->pt.total);
+  t->paths = take(t->path_stride * 2 * g.num_blocks);
+  t->total = o;
+  return DPTNAV_OK;
+}
+
+template <int N>
+int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const float* E, const float* Z,
+                      const float* d_s1, const float* d_s2, float* d_x, int B, int64_t T, int64_t L, int S) {
+  constexpr int GROUP = N / 4;
+  const dptnav_config& g = c->cfg;
+  hipStream_t st = br.st;
+  const int K = g.chunk_size, P = g.step_size;
+  const int64_t M = (int64_t)B * S * K, rows = (int64_t)2 * B * L;
+  const int ola = (int)((S - 1) * P + K), left = (int)((L - ola) / 2);
+  const int64_t ndec = (L - 1) * c->stride + g.kernel_size_enc;
+  const int pad_left = (int)((T - ndec) / 2);
+  float *DQ = br.ws + br.pl.dq, *DU = br.ws + br.pl.du, *DZs = br.ws + br.pl.dqkv, *LNP = br.ws + br.pl.lnp,
+        *slab = br.ws + br.pl.slab;
+  auto G = [&](const char* name) { return c->gptr[c->slot(name)]; };
+  int grid = 0;
+  // T2 recompute: q = OLA(Z) W_post^T + b_post + E ; d q, d decoder.weight
+  {
+    ALoadOla al{Z, N, B, (int)L, S, K, P, left, ola, 32};
+    EpiDecoderBwd<GROUP> ep{DQ, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"), d_s1, d_s2, LNP,
+                            (int64_t)B * L, T, (int)L, g.kernel_size_enc, c->stride, pad_left, 32};
+    if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_POST, "postproc recompute + decoder bwd",
+                                        c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32, 1, al, ep, nullptr, N, &grid))
+      return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 255) / 256), dim3(256), 0, st, LNP, grid, (int64_t)N * 8, slab, 0);
+    hipLaunchKernelGGL(decoder_wgrad_finish_kernel, dim3((N * g.kernel_size_enc + 255) / 256), dim3(256), 0, st, slab,
+                       G("decoder.weight"), N, g.kernel_size_enc);
+    LAUNCH_CHECK(c, "decoder weight grad");
+  }
+  br.slot = run.slot;
+  // post-processing conv gradients; d u = d q W_post
+  if (int rc = launch_colsum<N>(c, br, "d postproc bias", DQ, rows, N, 0, G("dprnn.postprocessing.0.bias"))) return rc;
+  {
+    ALoadCols yl{DQ, rows, N, 0, 32, false};
+    ALoadOla xl{Z, N, B, (int)L, S, K, P, left, ola, 32};
+    if (int rc = launch_wgrad<N, N>(c, br, "d postproc weight", (rows + 31) / 32, yl, xl, G("dprnn.postprocessing.0.weight")))
+      return rc;
+  }
+  run.slot = br.slot;
+  {
+    ALoadDense al{DQ, rows, N, 32};
+    EpiAddMaskStore ep{DU, nullptr, nullptr, rows, N, 32, N};
+    if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_POST, "d u", c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32,
+                                              1, al, ep, nullptr, N))
+      return rc;
+  }
+  br.slot = run.slot;
+  // overlap-add backward -> d Z ; separation conv gradients ; PReLU backward -> d x
+  hipLaunchKernelGGL(ola_grad_gather_kernel, dim3((unsigned)M), dim3(64), 0, st, DU, DZs, N, B, (int)L, S, K, P, left);
+  LAUNCH_CHECK(c, "ola backward");
+  if (int rc = launch_colsum<2 * N>(c, br, "d sep bias", DZs, M, 2 * N, 0, G("dprnn.speakers_separation.1.bias"))) return rc;
+  {
+    ALoadCols yl{DZs, M, 2 * N, 0, 32, false};
+    ALoadDensePReLU xl{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
+    if (int rc = launch_wgrad<2 * N, N>(c, br, "d sep weight", (M + 31) / 32, yl, xl, G("dprnn.speakers_separation.1.weight")))
+      return rc;
+  }
+  run.slot = br.slot;
+  {
+    ALoadDense al{DZs, M, 2 * N, 32};
+    EpiPReLUBwd ep{d_x, x, c->w("dprnn.speakers_separation.0.weight"), LNP, M, N, 32};
+    if (int rc = launch_gemm<2 * N, 1, 1, 4, true>(c, run, CAT_SEP, "d prelu", c->w("dprnn.speakers_separation.1.weight"),
+                                                  (M + 31) / 32, 1, al, ep, nullptr, N, &grid))
+      return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)1,
+                       G("dprnn.speakers_separation.0.weight"), 0);
+    LAUNCH_CHECK(c, "prelu slope grad");
+  }
+  br.slot = run.slot;
+  return DPTNAV_OK;
+}
+
+template <int N>
+int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* e1, const float* e2, const float* vid,
+                      const float* dX0, int B, int64_t T, int64_t L, int S, int Tv) {
+  const dptnav_config& g = c->cfg;
+  hipStream_t st = br.st;
+  constexpr int FPB = 256 / (N / 4);
+  float *DQ = br.ws + br.pl.dq, *DE = br.ws + br.pl.de, *DVI = br.ws + br.pl.dvi, *DV = br.ws + br.pl.dv,
+        *slab = br.ws + br.pl.slab, *red = br.ws + br.pl.lnp;
+  auto G = [&](const char* name) { return c->gptr[c->slot(name)]; };
+  const bool av = !g.audio_only;
+  const unsigned gx = (unsigned)((L + FPB - 1) / FPB);
+  hipLaunchKernelGGL(head_bwd_frames_kernel<N>, dim3(gx, B), dim3(256), 0, st, DQ, dX0, av ? vid : nullptr,
+                     av ? c->w("gate") : nullptr, av ? c->w("video_ln.weight") : nullptr, DE, DVI, slab, B, (int)L, Tv, S,
+                     g.chunk_size, g.step_size);
+  LAUNCH_CHECK(c, "head backward frames");
+  if (av) {
+    const int64_t cnt = 2 * N + 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, slab, (int)(gx * B), cnt, red, 0);
+    hipLaunchKernelGGL(gate_grad_finish_kernel, dim3(1), dim3(128), 0, st, red, c->w("gate"), c->w("video_ln.bias"), G("gate"),
+                       G("video_ln.weight"), G("video_ln.bias"), N);
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(Tv, B), dim3(128), 0, st, DVI, DV, N, (int)L, Tv);
+    hipLaunchKernelGGL(video_linear_bwd_kernel, dim3(g.hidden_video / 2), dim3(256), 0, st, DV, e1, e2,
+                       G("visual_compression.weight"), G("visual_compression.bias"), B, g.video_emb_size, Tv, g.hidden_video / 2);
+    LAUNCH_CHECK(c, "video branch backward");
+  }
+  {
+    const int fpb = 512;
+    const unsigned ex = (unsigned)((L + fpb - 1) / fpb);
+    hipLaunchKernelGGL(encoder_wgrad_kernel<N>, dim3(ex, B), dim3(256), 0, st, DE, mix, slab, B, T, (int)L, g.kernel_size_enc,
+                       c->stride, fpb);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 255) / 256), dim3(256), 0, st, slab, (int)(ex * B), (int64_t)N * 8, red, 0);
+    hipLaunchKernelGGL(decoder_wgrad_finish_kernel, dim3((N * g.kernel_size_enc + 255) / 256), dim3(256), 0, st, red,
+                       G("encoder.weight"), N, g.kernel_size_enc);
+    LAUNCH_CHECK(c, "encoder weight grad");
+  }
   return DPTNAV_OK;
 }
 
@@ -1136,6 +1282,94 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
   if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), br.st) != hipSuccess)
     return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
   return run_path_backward<128>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp);
+}
+
+// ---- training step, whole model -------------------------------------------------------------------------
+static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, ModelTape* mt, BwdPlan* bp) {
+  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
+    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (!h->cfg.bidir) return h->fail(DPTNAV_ERR_INVALID, "training step: bidir = False not supported yet");
+  if (int rc = make_plan(h, B, T, Tv, pl)) return rc;
+  make_model_tape(h, B, pl->L, (int)pl->S, Tv, mt);
+  make_bwd_plan(h, B, (int)pl->S, bp, pl->L, Tv);
+  return DPTNAV_OK;
+}
+size_t dptnav_train_tape_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
+  if (!h) return 0;
+  Plan pl; ModelTape mt; BwdPlan bp;
+  if (train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return 0;
+  return mt.total * sizeof(float);
+}
+size_t dptnav_train_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
+  if (!h) return 0;
+  Plan pl; ModelTape mt; BwdPlan bp;
+  if (train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return 0;
+  return (std::max(pl.total, bp.total)) * sizeof(float);
+}
+int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
+                         float* s1, float* s2, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  Plan pl; ModelTape mt; BwdPlan bp;
+  if (int rc = train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return rc;
+  if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
+  if (!tape || tape_bytes < mt.total * sizeof(float) || ((uintptr_t)tape & 255)) return h->fail(DPTNAV_ERR_WORKSPACE, "tape too small / misaligned");
+  if (!mix || !s1 || !s2 || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1))) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  Run run;
+  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  float* tb = (float*)tape;
+  if (int rc = run_head<128>(h, run, mix, e1, e2, B, T, Tv, tb + mt.E, tb + mt.X0, tb + mt.vid)) return rc;
+  const int nb = h->cfg.num_blocks;
+  for (int p = 0; p < 2 * nb; ++p) {
+    float* pt = tb + mt.paths + (size_t)p * mt.path_stride;
+    PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run.ws + pl.pre, pt + mt.pt.hc, pt + mt.pt.gates,
+                pt + mt.pt.cst, true};
+    if (int rc = run_path<128>(h, run, p / 2, p % 2, tb + mt.X0 + (size_t)p * mt.x_stride,
+                               tb + mt.X0 + (size_t)(p + 1) * mt.x_stride, B, (int)pl.S, &pb))
+      return rc;
+  }
+  // tail: Z (separation-conv output) is needed again by the backward -> kept on the tape
+  return run_tail<128>(h, run, tb + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb + mt.E, B, T, s1, s2, tb + mt.Z);
+}
+int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, const float* e2, const float* d_s1,
+                          const float* d_s2, int B, int64_t T, int Tv, void* tape, size_t tape_bytes, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  Plan pl; ModelTape mt; BwdPlan bp;
+  if (int rc = train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return rc;
+  if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "weights not bound");
+  if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
+  if (!tape || tape_bytes < mt.total * sizeof(float) || !ws || ws_bytes < bp.total * sizeof(float) || ((uintptr_t)ws & 255))
+    return h->fail(DPTNAV_ERR_WORKSPACE, "tape or workspace too small / misaligned");
+  if (!mix || !d_s1 || !d_s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  hipStream_t st = (hipStream_t)stream;
+  BwdRun br{(float*)ws, bp, st, 0};
+  if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st) != hipSuccess)
+    return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+  Run run;
+  run.ws = br.ws;
+  run.pl = Plan{};
+  run.pl.queue = bp.queue;
+  run.st = st;
+  run.slot = 0;
+  float* tb = (float*)tape;
+  const int nb = h->cfg.num_blocks, S = (int)pl.S;
+  float* dcur = br.ws + bp.dxa;
+  float* dnext = br.ws + bp.dxb;
+  if (int rc = run_tail_backward<128>(h, br, run, tb + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb + mt.E, tb + mt.Z, d_s1, d_s2,
+                                      dcur, B, T, pl.L, S))
+    return rc;
+  for (int p = 2 * nb - 1; p >= 0; --p) {
+    if (br.slot > QUEUE_SLOTS - 64) {   // plenty of launches per path: recycle the ticket counters
+      if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st) != hipSuccess)
+        return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+      br.slot = 0;
+    }
+    float* pt = tb + mt.paths + (size_t)p * mt.path_stride;
+    if (int rc = run_path_backward<128>(h, br, p / 2, p % 2, tb + mt.X0 + (size_t)p * mt.x_stride, dcur, dnext, B, S, pt, mt.pt))
+      return rc;
+    std::swap(dcur, dnext);
+  }
+  return run_head_backward<128>(h, br, mix, e1, e2, tb + mt.vid, dcur, B, T, pl.L, S, Tv);
 }
 
 // ---- tuning / diagnostic knobs ----------------------------------------------------------------------

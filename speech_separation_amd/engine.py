@@ -218,6 +218,42 @@ class DptnEngine:
             self._raise(rc, "dptnav_train_path_backward")
         return dx
 
+    # ------------------------------------------------------------------ training step, whole model
+    def train_forward(self, mix, e1=None, e2=None):
+        """Forward that records the tape; returns (s1_pred, s2_pred, tape)."""
+        B, T = mix.shape
+        mix = _check(mix, "mix", (B, T), self.device)
+        Tv = 1 if self.cfg.audio_only else e1.shape[-1]
+        if not self.cfg.audio_only:
+            e1 = _check(e1, "s1_embedding", (B, self.cfg.video_emb_size, Tv), self.device)
+            e2 = _check(e2, "s2_embedding", (B, self.cfg.video_emb_size, Tv), self.device)
+        nt = int(self.lib.dptnav_train_tape_bytes(self._h, B, T, Tv))
+        nw = int(self.lib.dptnav_train_workspace_bytes(self._h, B, T, Tv))
+        if nt == 0 or nw == 0:
+            raise RuntimeError(f"training step unsupported: {self.lib.dptnav_last_error(self._h).decode()}")
+        tape = torch.empty(nt, dtype=torch.uint8, device=self.device)
+        if getattr(self, "_tws", None) is None or self._tws.numel() < nw:
+            self._tws = torch.empty(nw, dtype=torch.uint8, device=self.device)
+        s1, s2 = torch.empty_like(mix), torch.empty_like(mix)
+        rc = self.lib.dptnav_train_forward(self._h, mix.data_ptr(), _ptr(e1), _ptr(e2), B, T, Tv, s1.data_ptr(), s2.data_ptr(),
+                                           tape.data_ptr(), tape.numel(), self._tws.data_ptr(), self._tws.numel(),
+                                           self._stream())
+        if rc:
+            self._raise(rc, "dptnav_train_forward")
+        return s1, s2, tape
+
+    def train_backward(self, mix, e1, e2, d_s1, d_s2, tape):
+        """Writes every parameter gradient into the buffers of bind_grads()."""
+        B, T = mix.shape
+        Tv = 1 if self.cfg.audio_only else e1.shape[-1]
+        d_s1 = _check(d_s1, "d_s1_pred", (B, T), self.device)
+        d_s2 = _check(d_s2, "d_s2_pred", (B, T), self.device)
+        rc = self.lib.dptnav_train_backward(self._h, mix.data_ptr(), _ptr(e1), _ptr(e2), d_s1.data_ptr(), d_s2.data_ptr(), B,
+                                            T, Tv, tape.data_ptr(), tape.numel(), self._tws.data_ptr(), self._tws.numel(),
+                                            self._stream())
+        if rc:
+            self._raise(rc, "dptnav_train_backward")
+
     # ------------------------------------------------------------------ loss / metric statistics
     def sisnr_pairs(self, s1_pred, s2_pred, s1, s2, mix) -> torch.Tensor:
         """(B,6,2) device tensor: [metric dB, loss term] for the pairs (p1,s1) (p1,s2) (p2,s1) (p2,s2) (mix,s1) (mix,s2)."""

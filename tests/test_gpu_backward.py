@@ -68,3 +68,50 @@ def test_path_backward_matches_autograd(dev, path):
         got = grads[pre + leaf].cpu().numpy()
         assert got.shape == tuple(gref.shape), leaf
         assert O.agreement_db(got, gref.numpy()) > 70, (leaf, O.agreement_db(got, gref.numpy()))
+
+
+@pytest.mark.parametrize("audio_only", [False, True])
+def test_whole_model_backward_matches_autograd(dev, audio_only):
+    """d loss / d every parameter for a 2-block model: libdptnav train_forward/backward vs torch.autograd (fp64, CPU)."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import synthetic_inputs
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0, "audio_only": audio_only})
+    sd = synthetic_state_dict(cfg, seed=2)
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(sd, dev))
+    grads = eng.bind_grads()
+    B, T, Tv = 2, 2000, 9
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=6)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    rng = np.random.default_rng(3)
+    d1 = rng.standard_normal((B, T)).astype(np.float32)
+    d2 = rng.standard_normal((B, T)).astype(np.float32)
+    s1, s2, tape = eng.train_forward(t["mix"], t.get("s1_embedding"), t.get("s2_embedding"))
+    f1, f2 = eng.forward(t["mix"], t.get("s1_embedding"), t.get("s2_embedding"))
+    assert O.agreement_db(s1.cpu().numpy(), f1.cpu().numpy()) > 110 and O.agreement_db(s2.cpu().numpy(), f2.cpu().numpy()) > 110
+    eng.train_backward(t["mix"], t.get("s1_embedding"), t.get("s2_embedding"), torch.from_numpy(d1).to(dev),
+                       torch.from_numpy(d2).to(dev), tape)
+    torch.cuda.synchronize()
+
+    ref = StockDPTN(cfg, sd)
+    ref.sd = {k: v.double().requires_grad_(True) for k, v in ref.sd.items()}
+    ref.paths = [(pre, m.double() if m is not None else None, r.double()) for pre, m, r in ref.paths]
+    for _, m, r in ref.paths:
+        for p in list(m.parameters()) + list(r.parameters()):
+            p.requires_grad_(True)
+    with torch.enable_grad():
+        out = StockDPTN.__call__.__wrapped__(ref, **{k: torch.from_numpy(v).double() for k, v in inp.items()})
+        (out["s1_pred"] * torch.from_numpy(d1).double() + out["s2_pred"] * torch.from_numpy(d2).double()).sum().backward()
+    want = {}
+    for pre, m, r in ref.paths:
+        want[pre + "mha.in_proj_weight"], want[pre + "mha.in_proj_bias"] = m.in_proj_weight.grad, m.in_proj_bias.grad
+        want[pre + "mha.out_proj.weight"], want[pre + "mha.out_proj.bias"] = m.out_proj.weight.grad, m.out_proj.bias.grad
+        for k, v in r.named_parameters():
+            want[pre + "rnn." + k] = v.grad
+    for k, v in ref.sd.items():
+        if k not in want and v.grad is not None:
+            want[k] = v.grad
+    missing = [k for k in grads if k not in want]
+    assert not missing, missing
+    worst = min((O.agreement_db(grads[k].cpu().numpy(), want[k].numpy().reshape(grads[k].shape)), k) for k in grads)
+    assert worst[0] > 60, worst
