@@ -12,8 +12,9 @@ Mirrors (does not import) the reference interface for this path:
   * ``str(model)`` ends with the two parameter-count lines of dptn_wav.py:196-207.
 
 Select it from the reference's Hydra CLI with ``model._target_=speech_separation_amd.DPTNAVWavEncDec``
-(INTEGRATION.md).  The forward runs ONLY on the HIP library: no PyTorch operators are used for compute
-and there is no CPU fallback -- a missing extension or a CPU tensor raises.
+(INTEGRATION.md).  The forward AND the backward of the model run ONLY on the HIP library (a torch.autograd.Function
+hands autograd the parameter gradients computed by dptnav_train_backward): no PyTorch operators are used for the
+model's compute and there is no CPU fallback -- a missing extension or a CPU tensor raises.
 """
 from __future__ import annotations
 
@@ -68,6 +69,31 @@ def _init_like_torch(key: str, p: torch.Tensor, cfg: DPTNConfig) -> None:
             p.uniform_(-b, b)
 
 
+class _SeparateFn(torch.autograd.Function):
+    """Model part of the training step: forward records a tape in libdptnav, backward turns d loss / d predictions into
+    the gradient of every parameter (dptnav_train_backward).  Loss, clipping and optimizer stay ordinary PyTorch code
+    of the caller (the reference's trainer.py:43-51)."""
+
+    @staticmethod
+    def forward(ctx, module, mix, e1, e2, *params):
+        eng = module._get_engine(mix.device)
+        if getattr(eng, "_grads", None) is None:
+            eng.bind_grads()
+        s1, s2, tape = eng.train_forward(mix, e1, e2)
+        ctx.module, ctx.tape, ctx.inputs = module, tape, (mix, e1, e2)
+        return s1, s2
+
+    @staticmethod
+    def backward(ctx, d_s1, d_s2):
+        eng = ctx.module._engine
+        mix, e1, e2 = ctx.inputs
+        zeros = lambda g: torch.zeros_like(mix) if g is None else g.contiguous()
+        eng.train_backward(mix, e1, e2, zeros(d_s1), zeros(d_s2), ctx.tape)
+        ctx.tape = None
+        # the library's gradient buffers are reused by the next step: hand autograd its own copies
+        return (None, None, None, None) + tuple(eng._grads[k].clone() for k, _ in eng.slots)
+
+
 class _DPTNBase(nn.Module):
     def __init__(self, cfg: DPTNConfig):
         super().__init__()
@@ -106,9 +132,16 @@ class _DPTNBase(nn.Module):
 
     def _run(self, mix, e1, e2):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "libdptnav implements the forward (inference) path; the backward kernels for the training step "
-                "(BASELINE config 4, SURVEY.md 8f N1) are not built yet -- call under torch.no_grad()")
+            if self.cfg.arch != "dptn" or self.cfg.num_features != 128 or not self.cfg.bidir:
+                raise NotImplementedError("the training step (backward kernels) is built for the DPTN architecture with "
+                                          "num_features=128, bidir=True (BASELINE config 4); use torch.no_grad() here")
+            if self.training and self.cfg.dropout != 0.0:
+                raise NotImplementedError(
+                    "train-mode attention dropout (dptn.py:16-21) is not implemented in libdptnav: construct the model "
+                    "with dropout=0.0 (a legal constructor argument, SURVEY.md Appendix B) or call model.eval()")
+            s1, s2 = _SeparateFn.apply(self, mix.contiguous(), None if e1 is None else e1.contiguous(),
+                                       None if e2 is None else e2.contiguous(), *self.parameters())
+            return {"s1_pred": s1, "s2_pred": s2}
         eng = self._get_engine(mix.device)
         s1, s2 = eng.forward(mix, e1, e2)
         return {"s1_pred": s1, "s2_pred": s2}
