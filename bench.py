@@ -43,6 +43,8 @@ BATCH_PER_GPU = 16
 CONFIGS = {
     "dptn_av": (DPTN_AV, 16, 32000, "configs[2]: DPTN-AV (dptn_wav_av) forward, precomputed lip embeddings"),
     "dptn_audio": (DPTN_AUDIO, 16, 32000, "configs[1]: DPTN audio-only (dptn_wav) forward"),
+    "dptn_av_train": (DPTN_AV, 16, 32000, "configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), attention "
+                                          "dropout 0"),
     "dprnn_av": (DPRNN_AV, 32, 128000, "configs[4]: DPRNN-AV long utterance (8 s @ 16 kHz): reference DPRNNEncDec "
                                        "backbone + this repo's AV fusion head"),
 }
@@ -109,6 +111,62 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
                       + "; ".join(parts) + "; max over B reported"}
 
 
+def bench_train(args, env, cfg, B, T, workload):
+    """BASELINE configs[3]: one optimizer step per bench step (zero_grad, forward with tape, torch loss, HIP backward,
+    one flat-bucket RCCL all-reduce of the 17.8 MB of gradients when N > 1, clip, AdamW)."""
+    from speech_separation_amd import DPTNAVWavEncDec
+    from speech_separation_amd.train import SiSNRWavLoss, train_step
+    dev = env.device
+    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
+    kw["dropout"] = 0.0   # train-mode attention dropout is not implemented (SURVEY.md Appendix B: parity is checked at 0)
+    model = DPTNAVWavEncDec(**kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+    model = model.to(dev).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123 + env.rank)
+    batch0 = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    crit = SiSNRWavLoss()
+    log(f"rank {env.rank}/{env.world} on {dev}: training warm-up")
+    stats = None
+    for _ in range(args.warmup):
+        stats = train_step(model, dict(batch0), crit, opt, 10.0, env=env)
+    env.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = train_step(model, dict(batch0), crit, opt, 10.0, env=env)
+    torch.cuda.synchronize(dev)
+    env.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    eng = model._engine
+    eng.profile(True)
+    eng.profile_reset()
+    psteps = max(1, min(args.steps, 3))
+    for _ in range(psteps):
+        train_step(model, dict(batch0), crit, opt, 10.0, env=env)
+    prof = eng.profile_read()
+    eng.profile(False)
+    if env.rank == 0:
+        value = env.world * B * args.steps / elapsed
+        flops = 3.0 * eng.flops_per_mixture(T)            # forward + backward (dgrad + wgrad), recomputes not counted
+        print(json.dumps({
+            "metric": "mixtures/sec DPTN-AV training step (fwd + PIT SI-SNR loss + bwd + clip + AdamW)",
+            "value": round(value, 3), "unit": "mixtures/sec", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{workload}, batch={B} per GPU, T={T}, random-init weights (numpy seed 0)",
+                       "batch_per_gpu": B, "samples": T,
+                       "parallelism": f"dp{env.world} (one flat gradient all-reduce per step over RCCL)"},
+            "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": round(value / env.world * flops / 1e12, 3),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(value / env.world * flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "note": "algorithmic FLOPs = 3 x forward (612 GFLOP per mixture)"},
+            "kernels_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in prof.items()},
+            "last_step": stats}), flush=True)
+    env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +185,8 @@ def main():
     B, Tv = args.batch or B_default, 50
     if args.config != "dptn_av":
         args.no_cpu_baseline = True     # the CPU leg is only defined for the headline configuration
+    if args.config.endswith("_train"):
+        return bench_train(args, env, cfg, B, T, workload)
 
     sd = synthetic_state_dict(cfg, seed=0)                       # random-init weights of the named architecture
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=123 + env.rank)   # each rank: its own shard of mixtures

@@ -76,3 +76,43 @@ def test_two_rank_sharded_evaluation_equals_single_process():
     want = sum(O.si_snr_db(full["s1_pred"][i:i + 1], inp["s1"][i:i + 1]) for i in range(5))
     for r in res:
         assert abs(r[3][0] - want) < 1e-9 and r[3][1] == 5.0 and r[4] == 2.0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from speech_separation_amd.train import allreduce_gradients
+    env = DistEnv.from_environ(expected_world=world, backend="gloo", device="cpu")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    x = torch.arange(20, dtype=torch.float32).reshape(4, 5) / 10 + rank          # each rank: its own batch shard
+    model(x).pow(2).mean().backward()
+    allreduce_gradients(model, env)                                              # ONE flat-bucket collective
+    q.put((rank, [p.grad.numpy().copy() for p in model.parameters()]))   # numpy: pickled by value
+    env.close()
+
+
+def test_gradient_allreduce_is_the_mean_over_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    want = [torch.zeros_like(p) for p in model.parameters()]
+    for rank in range(world):
+        model.zero_grad()
+        x = torch.arange(20, dtype=torch.float32).reshape(4, 5) / 10 + rank
+        model(x).pow(2).mean().backward()
+        for w, p in zip(want, model.parameters()):
+            w += p.grad / world
+    for rank in range(world):
+        for got, w in zip(res[rank][1], want):
+            assert np.allclose(got, w.numpy(), atol=1e-6)
