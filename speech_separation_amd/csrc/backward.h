@@ -80,18 +80,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
 #pragma unroll
     for (int b = 0; b < Sh::CB; ++b) acc[a][b] = zero16();
 
+  // software pipeline as in the GEMM engine: the next tile's rows are fetched into registers while the current
+  // tile's MFMAs run; tickets double buffered in LDS
   constexpr int Y4 = NN / 4, X4 = KK / 4;
-  for (;;) {
-    __syncthreads();                                   // previous tile fully consumed
-    if (tid == 0) s_next[0] = (int)atomicAdd(queue, 1u);
+  constexpr int NY = (32 * Y4) / 256, NX = (32 * X4) / 256;
+  static_assert((32 * Y4) % 256 == 0 && (32 * X4) % 256 == 0, "staging map");
+  float4 py[NY], px[NX];
+  int ticket_ahead = 0;
+  if (tid == 0) {
+    s_next[0] = (int)atomicAdd(queue, 1u);
+    ticket_ahead = (int)atomicAdd(queue, 1u);
+  }
+  __syncthreads();
+  int tile = s_next[0];
+  if (tile < ntiles) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) py[i] = yl.load4(tile, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) px[i] = xl.load4(tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+  }
+  int par = 0;
+  while (tile < ntiles) {
+    __syncthreads();                                   // previous tile's fragments fully consumed
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * Sh::LDY + 4 * (idx % Y4)]) = py[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Xs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = px[i];
+    }
+    if (tid == 0) {
+      s_next[par ^ 1] = ticket_ahead;
+      ticket_ahead = (int)atomicAdd(queue, 1u);
+    }
     __syncthreads();
-    const int tile = s_next[0];
-    if (tile >= ntiles) break;
-    for (int idx = tid; idx < 32 * Y4; idx += 256)
-      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * Sh::LDY + 4 * (idx % Y4)]) = yl.load4(tile, idx / Y4, idx % Y4);
-    for (int idx = tid; idx < 32 * X4; idx += 256)
-      *reinterpret_cast<float4*>(&Xs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = xl.load4(tile, idx / X4, idx % X4);
-    __syncthreads();
+    const int next = s_next[par ^ 1];
+    if (next < ntiles) {
+#pragma unroll
+      for (int i = 0; i < NY; ++i) py[i] = yl.load4(next, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) px[i] = xl.load4(next, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+    }
     // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
@@ -107,6 +139,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
 #pragma unroll
         for (int j = 0; j < Sh::CB; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
     }
+    tile = next;
+    par ^= 1;
   }
   float* out = slab + (size_t)blockIdx.x * (NN * KK);
 #pragma unroll
@@ -143,14 +177,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y
   }
 }
 
-// out[i] (+)= sum_s slab[s][i], s in fixed order; scale applied to the sum
+// out[i] (+)= sum_s slab[s][i] in a FIXED association order (bit-reproducible): a block owns 32 consecutive elements,
+// its 8 slab-lanes each sum the slabs s = lane, lane+8, ... with four loads in flight, then the lanes are combined in
+// lane order.  (A single thread walking all slabs serially was latency-bound: ~10 % of the training step.)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t count,
                                                            float* __restrict__ out, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += slab[(size_t)k * count + i];
-  out[i] = accumulate ? out[i] + s : s;
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int k = sl;
+    for (; k + 24 < nslabs; k += 32) {
+      s0 += slab[(size_t)k * count + i];
+      s1 += slab[(size_t)(k + 8) * count + i];
+      s2 += slab[(size_t)(k + 16) * count + i];
+      s3 += slab[(size_t)(k + 24) * count + i];
+    }
+    for (; k < nslabs; k += 8) s0 += slab[(size_t)k * count + i];
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][e];
+    out[i] = accumulate ? out[i] + s : s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -271,11 +324,12 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
 template <int DH>
 struct AttnBwdShape {
   static constexpr int LD = DH + 4;
-  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (4 * LD + 3)); }
+  // two row arrays (K,V in phase A; Q,dO in phase B) + three per-query statistics
+  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (2 * LD + 3)); }
 };
 
 template <int DH, int NKB>
-__global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                                   const float* __restrict__ att,
                                                                   const float* __restrict__ datt,
                                                                   float* __restrict__ dqkv, int N, SeqGeom g,
@@ -283,11 +337,13 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
   using Sh = AttnBwdShape<DH>;
   constexpr int LD = Sh::LD, ROWS = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;
-  float* Ks = Qs + ROWS * LD;
+  // the two row arrays hold K,V during phase A and are re-staged with Q,dO for phase B (47 KiB instead of 94 KiB
+  // per workgroup at 160 rows -> three workgroups per CU instead of one)
+  float* Ks = smem;
   float* Vs = Ks + ROWS * LD;
-  float* Ds = Vs + ROWS * LD;          // dO
-  float* Ms = Ds + ROWS * LD;          // row max (log2 domain)
+  float* Qs = Ks;                      // phase B alias
+  float* Ds = Vs;                      // phase B alias (dO)
+  float* Ms = Vs + ROWS * LD;          // row max (log2 domain)
   float* Ls = Ms + ROWS;               // 1 / row sum
   float* Es = Ls + ROWS;               // delta
   const int tid = threadIdx.x;
@@ -299,23 +355,18 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
   const int ld3 = 3 * N;
   const float sl2e = scale * 1.4426950408889634f;
 
-  // ---- stage Q, K, V, dO rows of this (sequence, head); rows >= len are zero ------------------------
+  // ---- stage K, V rows of this (sequence, head); rows >= len are zero --------------------------------
   constexpr int R4 = DH / 4;
   for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
     const int p = idx / R4, f = idx % R4;
-    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, d4 = q4;
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
     if (p < len) {
-      const int64_t tok = tok0 + (int64_t)p * tstride;
-      const float* row = qkv + tok * ld3 + head * DH + 4 * f;
-      q4 = *reinterpret_cast<const float4*>(row);
+      const float* row = qkv + (tok0 + (int64_t)p * tstride) * ld3 + head * DH + 4 * f;
       k4 = *reinterpret_cast<const float4*>(row + N);
       v4 = *reinterpret_cast<const float4*>(row + 2 * N);
-      d4 = *reinterpret_cast<const float4*>(datt + tok * N + head * DH + 4 * f);
     }
-    *reinterpret_cast<float4*>(&Qs[p * LD + 4 * f]) = q4;
     *reinterpret_cast<float4*>(&Ks[p * LD + 4 * f]) = k4;
     *reinterpret_cast<float4*>(&Vs[p * LD + 4 * f]) = v4;
-    *reinterpret_cast<float4*>(&Ds[p * LD + 4 * f]) = d4;
   }
   __syncthreads();
 
@@ -326,16 +377,16 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
     float qf[DH / 2], df[DH / 2];
     float dsum = 0.f;
     {
-      const float* qrow = Qs + p * LD + 4 * hh;
-      const float* drow = Ds + p * LD + 4 * hh;
       const int64_t tok = tok0 + (int64_t)(p < len ? p : 0) * tstride;
+      const float* qrow = qkv + tok * ld3 + head * DH + 4 * hh;
+      const float* drow = datt + tok * N + head * DH + 4 * hh;
       const float* orow = att + tok * N + head * DH + 4 * hh;
 #pragma unroll
       for (int m = 0; m < DH / 8; ++m) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * m);
-        const float4 d4 = *reinterpret_cast<const float4*>(drow + 8 * m);
+        float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * m);
+        float4 d4 = *reinterpret_cast<const float4*>(drow + 8 * m);
         float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * m);
-        if (p >= len) o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p >= len) q4 = d4 = o4 = make_float4(0.f, 0.f, 0.f, 0.f);
         qf[4 * m + 0] = q4.x * sl2e; qf[4 * m + 1] = q4.y * sl2e; qf[4 * m + 2] = q4.z * sl2e; qf[4 * m + 3] = q4.w * sl2e;
         df[4 * m + 0] = d4.x; df[4 * m + 1] = d4.y; df[4 * m + 2] = d4.z; df[4 * m + 3] = d4.w;
         dsum += d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
@@ -395,16 +446,19 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
         dp = mfma32(v.z, df[4 * m + 2], dp);
         dp = mfma32(v.w, df[4 * m + 3], dp);
       }
-      float kk[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float kval = Ks[(rb * 32 + ROW32(r, hh)) * LD + (c < DH ? c : 0)];
-        kk[r] = c < DH ? kval : 0.f;
-      }
+      for (int r0 = 0; r0 < 16; r0 += 8) {      // K rows fetched 8 at a time (register budget: 3 waves per SIMD)
+        float kk[8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float ds = s[rb][r] * inv * (dp[r] - delta);
-        dq = mfma32(ds, kk[r], dq);
+        for (int r = 0; r < 8; ++r) {
+          const float kval = Ks[(rb * 32 + ROW32(r0 + r, hh)) * LD + (c < DH ? c : 0)];
+          kk[r] = c < DH ? kval : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float ds = s[rb][r0 + r] * inv * (dp[r0 + r] - delta);
+          dq = mfma32(ds, kk[r], dq);
+        }
       }
     }
 #pragma unroll
@@ -413,8 +467,6 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
       if (pq < len && c < DH) dqkv[(tok0 + (int64_t)pq * tstride) * ld3 + head * DH + c] = dq[r] * scale;
     }
   }
-  __syncthreads();
-
   // =================================== phase B: wave = key block =====================================
   {
     const int kb = wv;
@@ -422,16 +474,30 @@ __global__ __launch_bounds__(64 * NKB) void attention_bwd_kernel(const float* __
     const bool key_ok = key < len;
     float kf[DH / 2], vf[DH / 2];
     {
-      const float* krow = Ks + key * LD + 4 * hh;
-      const float* vrow = Vs + key * LD + 4 * hh;
+      const float* krow = qkv + (tok0 + (int64_t)(key_ok ? key : 0) * tstride) * ld3 + N + head * DH + 4 * hh;
 #pragma unroll
       for (int m = 0; m < DH / 8; ++m) {
-        const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * m);
-        const float4 v4 = *reinterpret_cast<const float4*>(vrow + 8 * m);
+        float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * m);
+        float4 v4 = *reinterpret_cast<const float4*>(krow + N + 8 * m);
+        if (!key_ok) k4 = v4 = make_float4(0.f, 0.f, 0.f, 0.f);
         kf[4 * m + 0] = k4.x; kf[4 * m + 1] = k4.y; kf[4 * m + 2] = k4.z; kf[4 * m + 3] = k4.w;
         vf[4 * m + 0] = v4.x; vf[4 * m + 1] = v4.y; vf[4 * m + 2] = v4.z; vf[4 * m + 3] = v4.w;
       }
     }
+    // every wave is done with K,V rows: overwrite the two arrays with Q and dO rows
+    __syncthreads();
+    for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
+      const int p = idx / R4, f = idx % R4;
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = q4;
+      if (p < len) {
+        const int64_t tok = tok0 + (int64_t)p * tstride;
+        q4 = *reinterpret_cast<const float4*>(qkv + tok * ld3 + head * DH + 4 * f);
+        d4 = *reinterpret_cast<const float4*>(datt + tok * N + head * DH + 4 * f);
+      }
+      *reinterpret_cast<float4*>(&Qs[p * LD + 4 * f]) = q4;
+      *reinterpret_cast<float4*>(&Ds[p * LD + 4 * f]) = d4;
+    }
+    __syncthreads();
     f32x16 dk = zero16(), dv = zero16();
 #pragma unroll 1
     for (int qb = 0; qb < NKB; ++qb) {

@@ -618,7 +618,7 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab);
   LAUNCH_CHECK(c, what);
   const int64_t count = (int64_t)NN * KK;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, br.st, slab, grid, count,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count,
                      grad, 0);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
@@ -632,8 +632,8 @@ int launch_colsum(dptnav_ctx* c, BwdRun& br, const char* what, const float* Y, i
   float* slab = br.ws + br.pl.slab;
   hipLaunchKernelGGL(colsum_kernel<C>, dim3(grid), dim3(256), 0, br.st, Y, M, ld, col0, slab);
   LAUNCH_CHECK(c, what);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad, 0);
-  if (grad2) hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad2, 0);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad, 0);
+  if (grad2) hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + 31) / 32), dim3(256), 0, br.st, slab, grid, (int64_t)C, grad2, 0);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -672,7 +672,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<2 * LSTM_H, 1, 1, 4>(c, run, CAT_FFN, "ffn recompute + ln2 bwd", w.ffn_w, ntiles, 1, al, ep,
                                                  nullptr, 2 * LSTM_H, &grid))
       return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
     hipMemcpyAsync(G("ln2.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(G("ln2.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
     LAUNCH_CHECK(c, "ln2 grads");
@@ -735,7 +735,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_OUTPROJ, "out-proj recompute + ln1 bwd", w.out_w, ntiles, 1, al, ep,
                                         nullptr, N, &grid))
       return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
     hipMemcpyAsync(G("ln1.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(G("ln1.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
     LAUNCH_CHECK(c, "ln1 grads");
@@ -849,7 +849,7 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
     if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_POST, "postproc recompute + decoder bwd",
                                         c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32, 1, al, ep, nullptr, N, &grid))
       return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 255) / 256), dim3(256), 0, st, LNP, grid, (int64_t)N * 8, slab, 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)N * 8, slab, 0);
     hipLaunchKernelGGL(decoder_wgrad_finish_kernel, dim3((N * g.kernel_size_enc + 255) / 256), dim3(256), 0, st, slab,
                        G("decoder.weight"), N, g.kernel_size_enc);
     LAUNCH_CHECK(c, "decoder weight grad");
@@ -914,7 +914,7 @@ int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* 
   LAUNCH_CHECK(c, "head backward frames");
   if (av) {
     const int64_t cnt = 2 * N + 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, slab, (int)(gx * B), cnt, red, 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, st, slab, (int)(gx * B), cnt, red, 0);
     hipLaunchKernelGGL(gate_grad_finish_kernel, dim3(1), dim3(128), 0, st, red, c->w("gate"), c->w("video_ln.bias"), G("gate"),
                        G("video_ln.weight"), G("video_ln.bias"), N);
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(Tv, B), dim3(128), 0, st, DVI, DV, N, (int)L, Tv);
@@ -927,7 +927,7 @@ int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* 
     const unsigned ex = (unsigned)((L + fpb - 1) / fpb);
     hipLaunchKernelGGL(encoder_wgrad_kernel<N>, dim3(ex, B), dim3(256), 0, st, DE, mix, slab, B, T, (int)L, g.kernel_size_enc,
                        c->stride, fpb);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 255) / 256), dim3(256), 0, st, slab, (int)(ex * B), (int64_t)N * 8, red, 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 31) / 32), dim3(256), 0, st, slab, (int)(ex * B), (int64_t)N * 8, red, 0);
     hipLaunchKernelGGL(decoder_wgrad_finish_kernel, dim3((N * g.kernel_size_enc + 255) / 256), dim3(256), 0, st, red,
                        G("encoder.weight"), N, g.kernel_size_enc);
     LAUNCH_CHECK(c, "encoder weight grad");

@@ -89,8 +89,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   // Tiles are handed out by a device-wide ticket counter (one per column group, zeroed by the host before the
   // launch) instead of a static grid-stride: when this kernel shares the chip with another stream's kernel
   // (dptnav_forward overlaps two half-batches), workgroups that start late simply find fewer tickets left.
+  // (thread 0 always holds the ticket AFTER the next one in a register, so the atomic's round trip -- a microsecond
+  // when exposed in front of a barrier -- overlaps a whole tile of MFMAs)
   unsigned* queue = tile_queue + colgroup;
-  if (tid == 0) s_next[0] = (int)atomicAdd(queue, 1u);
+  int ticket_ahead = 0;
+  if (tid == 0) {
+    s_next[0] = (int)atomicAdd(queue, 1u);
+    ticket_ahead = (int)atomicAdd(queue, 1u);
+  }
   __syncthreads();
   float4 pf[NLD];
   int tile = s_next[0];
@@ -104,7 +110,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   int buf = 0;
   while (tile < ntiles) {
     float* Ab = As + buf * (Sh::BM * Sh::LDA);
-    if (tid == 0) s_next[buf ^ 1] = (int)atomicAdd(queue, 1u);   // ticket of the next iteration
+    if (tid == 0) {                                            // publish the next ticket, request the one after it
+      s_next[buf ^ 1] = ticket_ahead;
+      ticket_ahead = (int)atomicAdd(queue, 1u);
+    }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
