@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
                                                          const float* __restrict__ tape_c,
                                                          const float* __restrict__ whh_f, const float* __restrict__ whh_b,
                                                          const float* __restrict__ dh_up, int ldh,
-                                                         float* __restrict__ dg_out, int ldg, int dump_row, SeqGeom g) {
+                                                         float* __restrict__ dg_out, int ldg, int dump_row, SeqGeom g,
+                                                         float* __restrict__ bias_partials /* [ndir][nst][512] */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* DPs = smem;   // [2][32][BPTT_LDP]
   const int tid = threadIdx.x;
@@ -249,8 +250,12 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
     gidx[r] = tokb * (unsigned)ldg + (unsigned)(d * 512 + 32 * w + c);
   }
   const unsigned hstep = (unsigned)(tdir * tstride * ldh), gstep = (unsigned)(tdir * tstride * ldg);
-  const bool row_ok_any = true;
-  (void)row_ok_any;
+  // bias gradients (b_ih and b_hh share them) = column sums of dP over valid rows and steps: accumulated here, one
+  // partial row per workgroup, instead of re-reading the 1.4 GB of dP with a column-sum kernel
+  unsigned vmask = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) vmask |= (st * 32 + ROW32(r, hh) < g.nseq ? 1u : 0u) << r;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   f32x16 dh_rec = zero16(), dc_rec = zero16();
   for (int step = 0; step < g.len; ++step) {
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
         const float dpf = dc * pv[e] * fv[e] * (1.f - fv[e]);
         const float dpg = dc * iv[e] * (1.f - gv[e] * gv[e]);
         dc_rec[r] = dc * fv[e];
+        if ((vmask >> r) & 1u) { bsum[0] += dpi; bsum[1] += dpf; bsum[2] += dpg; bsum[3] += dpo; }
         const int row = ROW32(r, hh);
         float* lp = dp + row * BPTT_LDP + 32 * w + c;
         lp[0] = dpi; lp[128] = dpf; lp[256] = dpg; lp[384] = dpo;
@@ -311,6 +317,11 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
     }
     dh_rec = acc;
   }
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const float v = bsum[gi] + __shfl_xor(bsum[gi], 32);
+    if (hh == 0) bias_partials[((size_t)d * g.nst + st) * 512 + gi * LSTM_H + 32 * w + c] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,12 +339,14 @@ struct AttnBwdShape {
   static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (2 * LD + 3)); }
 };
 
-template <int DH, int NKB>
+// PHASE 0 and PHASE 1 are separate launches (each gets its own register allocation: together they needed 170 VGPRs,
+// two short of three waves per SIMD); the per-query statistics travel through `stats` [token][head][4].
+template <int DH, int NKB, int PHASE>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                                   const float* __restrict__ att,
                                                                   const float* __restrict__ datt,
-                                                                  float* __restrict__ dqkv, int N, SeqGeom g,
-                                                                  float scale) {
+                                                                  float* __restrict__ dqkv, float* __restrict__ stats,
+                                                                  int heads, int N, SeqGeom g, float scale) {
   using Sh = AttnBwdShape<DH>;
   constexpr int LD = Sh::LD, ROWS = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -355,8 +368,9 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   const int ld3 = 3 * N;
   const float sl2e = scale * 1.4426950408889634f;
 
-  // ---- stage K, V rows of this (sequence, head); rows >= len are zero --------------------------------
   constexpr int R4 = DH / 4;
+  if constexpr (PHASE == 0) {
+  // ---- stage K, V rows of this (sequence, head); rows >= len are zero --------------------------------
   for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
     const int p = idx / R4, f = idx % R4;
     float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
@@ -427,11 +441,8 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    if (hh == 0) {
-      Ms[p] = mx;
-      Ls[p] = inv;
-      Es[p] = delta;
-    }
+    if (hh == 0 && p < len)
+      *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) = make_float4(mx, inv, delta, 0.f);
     // dS^T tile by tile, then dQ = scale * dS K
     f32x16 dq = zero16();
 #pragma unroll
@@ -467,6 +478,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       if (pq < len && c < DH) dqkv[(tok0 + (int64_t)pq * tstride) * ld3 + head * DH + c] = dq[r] * scale;
     }
   }
+  } else {
   // =================================== phase B: wave = key block =====================================
   {
     const int kb = wv;
@@ -484,8 +496,14 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         vf[4 * m + 0] = v4.x; vf[4 * m + 1] = v4.y; vf[4 * m + 2] = v4.z; vf[4 * m + 3] = v4.w;
       }
     }
-    // every wave is done with K,V rows: overwrite the two arrays with Q and dO rows
-    __syncthreads();
+    // stage Q and dO rows and the per-query statistics of phase A
+    for (int p = tid; p < ROWS; p += 64 * NKB) {
+      float4 st4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < len) st4 = *reinterpret_cast<const float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4);
+      Ms[p] = st4.x;
+      Ls[p] = st4.y;
+      Es[p] = st4.z;
+    }
     for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
       const int p = idx / R4, f = idx % R4;
       float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = q4;
@@ -544,5 +562,6 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         row[2 * N] = dv[r];
       }
     }
+  }
   }
 }

@@ -703,7 +703,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     }
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(lstm_bptt_kernel, dim3(geom.nst, 2), dim3(256), BPTT_LDS_BYTES, st, gates, cst, w.w_hh[0], w.w_hh[1],
-                       DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom);
+                       DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom, LNP);
     LAUNCH_CHECK(c, "lstm bptt");
   }
   // 5. LSTM parameter gradients
@@ -711,7 +711,12 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     const char* sfx = d ? "_reverse" : "";
     const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
                       bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
-    if (int rc = launch_colsum<512>(c, br, "d lstm bias", DG, M, 2 * 512, d * 512, G(bih.c_str()), G(bhh.c_str()))) return rc;
+    // bias gradients: per-workgroup partial rows written by the BPTT kernel
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * geom.nst * 512, geom.nst,
+                       (int64_t)512, G(bih.c_str()), 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * geom.nst * 512, geom.nst,
+                       (int64_t)512, G(bhh.c_str()), 0);
+    LAUNCH_CHECK(c, "d lstm bias");
     ALoadDense xl{y1, M, N, 32};
     ALoadSeqShift hl{hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom};
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
@@ -759,24 +764,30 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   {
     const int nkb = (geom.len + 31) / 32;
     const float scale = 1.0f / sqrtf((float)DH);
-    auto launch = [&](auto kern, int threads) -> int {
+    float* stats = DATT == nullptr ? nullptr : br.ws + br.pl.dy1;   // dy1 is dead by now: reuse it for [token][head][4]
+    auto launch = [&](auto kern0, auto kern1, int threads) -> int {
       const size_t lds = AttnBwdShape<DH>::lds_bytes(nkb);
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "attention bwd lds: %s", hipGetErrorString(e));
       ProfScope ps(c, CAT_ATTN, st);
-      hipLaunchKernelGGL(kern, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, N, geom, scale);
+      hipLaunchKernelGGL(kern0, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
+                         geom, scale);
+      hipLaunchKernelGGL(kern1, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
+                         geom, scale);
       return DPTNAV_OK;
     };
     int rc = DPTNAV_OK;
     switch (nkb) {
-      case 1: rc = launch(attention_bwd_kernel<DH, 1>, 64); break;
-      case 2: rc = launch(attention_bwd_kernel<DH, 2>, 128); break;
-      case 3: rc = launch(attention_bwd_kernel<DH, 3>, 192); break;
-      case 4: rc = launch(attention_bwd_kernel<DH, 4>, 256); break;
-      case 5: rc = launch(attention_bwd_kernel<DH, 5>, 320); break;
-      case 6: rc = launch(attention_bwd_kernel<DH, 6>, 384); break;
-      case 7: rc = launch(attention_bwd_kernel<DH, 7>, 448); break;
-      case 8: rc = launch(attention_bwd_kernel<DH, 8>, 512); break;
+      case 1: rc = launch(attention_bwd_kernel<DH, 1, 0>, attention_bwd_kernel<DH, 1, 1>, 64); break;
+      case 2: rc = launch(attention_bwd_kernel<DH, 2, 0>, attention_bwd_kernel<DH, 2, 1>, 128); break;
+      case 3: rc = launch(attention_bwd_kernel<DH, 3, 0>, attention_bwd_kernel<DH, 3, 1>, 192); break;
+      case 4: rc = launch(attention_bwd_kernel<DH, 4, 0>, attention_bwd_kernel<DH, 4, 1>, 256); break;
+      case 5: rc = launch(attention_bwd_kernel<DH, 5, 0>, attention_bwd_kernel<DH, 5, 1>, 320); break;
+      case 6: rc = launch(attention_bwd_kernel<DH, 6, 0>, attention_bwd_kernel<DH, 6, 1>, 384); break;
+      case 7: rc = launch(attention_bwd_kernel<DH, 7, 0>, attention_bwd_kernel<DH, 7, 1>, 448); break;
+      case 8: rc = launch(attention_bwd_kernel<DH, 8, 0>, attention_bwd_kernel<DH, 8, 1>, 512); break;
       default: return c->fail(DPTNAV_ERR_INVALID, "attention bwd: sequence length %d > 256", geom.len);
     }
     if (rc) return rc;
