@@ -44,7 +44,7 @@ CONFIGS = {
     "dptn_av": (DPTN_AV, 16, 32000, "configs[2]: DPTN-AV (dptn_wav_av) forward, precomputed lip embeddings"),
     "dptn_audio": (DPTN_AUDIO, 16, 32000, "configs[1]: DPTN audio-only (dptn_wav) forward"),
     "dptn_av_train": (DPTN_AV, 16, 32000, "configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), attention "
-                                          "dropout 0"),
+                                          "dropout 0.1"),
     "dprnn_av": (DPRNN_AV, 32, 128000, "configs[4]: DPRNN-AV long utterance (8 s @ 16 kHz): reference DPRNNEncDec "
                                        "backbone + this repo's AV fusion head"),
 }
@@ -117,8 +117,7 @@ def bench_train(args, env, cfg, B, T, workload):
     from speech_separation_amd import DPTNAVWavEncDec
     from speech_separation_amd.train import SiSNRWavLoss, train_step
     dev = env.device
-    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
-    kw["dropout"] = 0.0   # train-mode attention dropout is not implemented (parity is checked at 0)
+    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}   # dropout 0.1 as in dptn_wav_av.yaml
     model = DPTNAVWavEncDec(**kw)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
     model = model.to(dev).train()

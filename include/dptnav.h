@@ -158,7 +158,7 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
  *   (src/trainer/trainer.py:47): given d loss / d s1_pred and d loss / d s2_pred it WRITES the gradient of every
  *   parameter into the buffers bound with dptnav_bind_grads.  The loss itself (src/loss/ss_losses.py), gradient
  *   clipping and the optimizer stay the reference's own PyTorch code (speech_separation_amd/model.py wraps these two
- *   calls in a torch.autograd.Function).  Attention dropout must be 0. */
+ *   calls in a torch.autograd.Function).  Train-mode attention dropout: options dropout_ppm / dropout_seed below. */
 size_t dptnav_train_tape_bytes(dptnav_handle h, int B, int64_t T, int Tv);
 size_t dptnav_train_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv);
 int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
@@ -168,10 +168,18 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
                           const float* d_s2_pred, int B, int64_t T, int Tv, void* tape, size_t tape_bytes,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* Test helper: mask (nseq, heads, len, len) fp32 of ones/zeros = the keep-mask of path (block, path). */
+int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, float* mask, void* stream);
+
 /* Tuning / diagnostic knobs (never needed for correct results).  Keys:
  *   "overlap" (0/1, default 1): dptnav_forward runs the batch as two halves on two internal streams (forked from
  *                 and joined to the caller's stream by events) so that one half's GEMM/attention launches fill the
  *                 CUs the other half's LSTM recurrence cannot use; 0 = everything on the caller's stream.
+ *   "dropout_ppm" (0..999999), "dropout_seed": train-mode dropout of the attention probabilities (dptn.py:16-21,
+ *                 nn.MultiheadAttention(dropout=0.1)) for dptnav_train_forward/backward.  The keep-mask is a counter-based
+ *                 hash of (seed, block, path, query token, head, key position): reproducible, identical in forward and
+ *                 backward, but NOT PyTorch's Philox stream (parity with the reference is statistical only).  The caller
+ *                 changes the seed every step and sets the same seed for the backward of that step.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
  *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
 int dptnav_set_option(dptnav_handle h, const char* key, int value);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "dptnav_train_workspace_bytes": (_sz, [_vp, _i, _i64, _i]),
     "dptnav_train_forward": (_i, [_vp, _fp, _fp, _fp, _i, _i64, _i, _fp, _fp, _vp, _sz, _vp, _sz, _vp]),
     "dptnav_train_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i, _vp, _sz, _vp, _sz, _vp]),
+    "dptnav_dropout_mask": (_i, [_vp, _i, _i, _i, _i, _fp, _vp]),
     "dptnav_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dptnav_profile_enable": (_i, [_vp, _i]),
     "dptnav_profile_collect": (_i, [_vp]),

@@ -27,7 +27,7 @@ struct AttnShape {
 template <int DH, int NKB>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_kernel(const float* __restrict__ qkv,
                                                               float* __restrict__ out, int N, SeqGeom g,
-                                                              float scale_log2e) {
+                                                              float scale_log2e, DropCfg drop) {
   using Sh = AttnShape<DH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                        // [NKB*32][LDK]
@@ -121,6 +121,14 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     }
   sum += __shfl_xor(sum, 32);
   const float inv = fast_rcp(sum);
+  if (drop.thresh != 0u) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
+    const uint32_t qh = (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)gridDim.y + (uint32_t)head;
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[rb][r] = drop_rand(drop.seed, qh, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
+  }
 
   // ---- O = P V: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them ----
   f32x16 o = zero16();

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
                                                                   const float* __restrict__ att,
                                                                   const float* __restrict__ datt,
                                                                   float* __restrict__ dqkv, float* __restrict__ stats,
-                                                                  int heads, int N, SeqGeom g, float scale) {
+                                                                  int heads, int N, SeqGeom g, float scale, DropCfg drop) {
   using Sh = AttnBwdShape<DH>;
   constexpr int LD = Sh::LD, ROWS = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     if (hh == 0 && p < len)
       *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) = make_float4(mx, inv, delta, 0.f);
     // dS^T tile by tile, then dQ = scale * dS K
+    const uint32_t qh = (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head;
     f32x16 dq = zero16();
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb) {
@@ -467,7 +468,10 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const float ds = s[rb][r0 + r] * inv * (dp[r0 + r] - delta);
+          float dpv = dp[r0 + r];
+          if (drop.thresh != 0u)
+            dpv = drop_rand(drop.seed, qh, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dpv * drop.inv_keep : 0.f;
+          const float ds = s[rb][r0 + r] * inv * (dpv - delta);
           dq = mfma32(ds, kk[r], dq);
         }
       }
@@ -541,8 +545,13 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         const int qrow_i = qb * 32 + ROW32(r, hh);
         const float pm = Ms[qrow_i], pl = Ls[qrow_i], pe = Es[qrow_i];
         const float p2 = key_ok ? fast_exp2(s2[r] * sl2e - pm) * pl : 0.f;
-        s2[r] = p2;                          // P
-        dp2[r] = p2 * (dp2[r] - pe);         // dS
+        float keep = 1.f;
+        if (drop.thresh != 0u) {
+          const uint32_t qh = (uint32_t)(tok0 + (int64_t)qrow_i * tstride) * (uint32_t)heads + (uint32_t)head;
+          keep = drop_rand(drop.seed, qh, (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
+        }
+        s2[r] = p2 * keep;                          // dropped P (feeds dV)
+        dp2[r] = p2 * (dp2[r] * keep - pe);         // dS
         const float qv = Qs[qrow_i * LD + (c < DH ? c : 0)], dv_ = Ds[qrow_i * LD + (c < DH ? c : 0)];
         qq[r] = c < DH ? qv : 0.f;
         dd[r] = c < DH ? dv_ : 0.f;
@@ -563,5 +572,19 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       }
     }
   }
+  }
+}
+
+// test helper: materialise the dropout keep-mask exactly as the attention kernels regenerate it
+//   mask[seq][head][query][key] in {0,1}
+__global__ void dropout_mask_kernel(float* __restrict__ mask, SeqGeom g, int heads, DropCfg drop) {
+  const int seq = blockIdx.x, head = blockIdx.y;
+  const int64_t tok0 = seq_token_base(g, seq);
+  const int tstride = seq_token_stride(g);
+  for (int idx = threadIdx.x; idx < g.len * g.len; idx += blockDim.x) {
+    const int q = idx / g.len, k = idx - q * g.len;
+    const uint32_t qh = (uint32_t)(tok0 + (int64_t)q * tstride) * (uint32_t)heads + (uint32_t)head;
+    mask[(((int64_t)seq * heads + head) * g.len + q) * g.len + k] =
+        drop.thresh == 0u || drop_rand(drop.seed, qh, (uint32_t)k) >= drop.thresh ? 1.f : 0.f;
   }
 }

@@ -60,6 +60,22 @@ DEV float group_sum(float v) {
   return v;
 }
 
+// Counter-based dropout randomness for the attention probabilities (train mode, dptn.py:16-21): a pure function of
+// (seed, query token x head, key position), so the forward and both backward phases regenerate identical masks.
+// keep  <=>  drop_rand(...) >= thresh,  thresh = p * 2^32.   (lowbias32 mixer)
+DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+DEV uint32_t drop_rand(uint32_t seed, uint32_t qtok_head, uint32_t key) {
+  return mix32(mix32(seed ^ (qtok_head * 0x9E3779B9u)) ^ (key * 0x85EBCA6Bu + 0x165667B1u));
+}
+struct DropCfg {
+  uint32_t seed;     // already mixed with the call index (block, path, step)
+  uint32_t thresh;   // 0: no dropout
+  float inv_keep;    // 1 / (1 - p)
+};
+
 // LDS-DMA: 64 lanes x 16 B from per-lane global addresses to wave-uniform LDS base + lane*16 (no VGPR hop).
 DEV void glds16(const float* gsrc, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

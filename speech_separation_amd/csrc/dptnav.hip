@@ -71,6 +71,17 @@ struct dptnav_ctx {
   bool prof_on = false;
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
+  int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
+  unsigned opt_dropout_seed = 0;
+  DropCfg drop_cfg(int block, int path, bool train) const {
+    DropCfg d{0u, 0u, 1.0f};
+    if (!train || opt_dropout_ppm <= 0) return d;
+    const double p = opt_dropout_ppm * 1e-6;
+    d.seed = opt_dropout_seed ^ (0x9E3779B9u * (unsigned)(2 * block + path + 1));
+    d.thresh = (unsigned)(p * 4294967296.0);
+    d.inv_keep = (float)(1.0 / (1.0 - p));
+    return d;
+  }
   hipStream_t streams[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
   int ensure_streams() {
@@ -310,7 +321,7 @@ inline int cap_grid(int64_t ntiles, int cap) { return (int)(ntiles < cap ? ntile
 // ---- attention dispatch over the number of 32-key blocks ----------------------------------------
 template <int DH, int NKB>
 int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads,
-                    hipStream_t st) {
+                    hipStream_t st, DropCfg drop) {
   auto kern = attention_kernel<DH, NKB>;
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
   static bool ready = false;
@@ -320,21 +331,22 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
   }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
-  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale);
+  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale, drop);
   LAUNCH_CHECK(c, "attention");
   return DPTNAV_OK;
 }
 template <int DH>
-int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads, hipStream_t st) {
+int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads, hipStream_t st,
+                DropCfg drop = DropCfg{0u, 0u, 1.0f}) {
   switch ((g.len + 31) / 32) {
-    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st);
-    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st);
-    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st);
-    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st);
-    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st);
-    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st);
-    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st);
-    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st);
+    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st, drop);
+    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st, drop);
+    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st, drop);
+    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st, drop);
+    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st, drop);
+    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st, drop);
+    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop);
+    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop);
   }
   return c->fail(DPTNAV_ERR_INVALID, "attention: sequence length %d > 256", g.len);
 }
@@ -406,7 +418,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (dptn)
-    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st)) return rc;
+    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train))) return rc;
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
   if (dptn) {
     ALoadDense al{att, M, N, BM};
@@ -772,10 +784,11 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "attention bwd lds: %s", hipGetErrorString(e));
       ProfScope ps(c, CAT_ATTN, st);
+      const DropCfg drop = c->drop_cfg(block, path, true);
       hipLaunchKernelGGL(kern0, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale);
+                         geom, scale, drop);
       hipLaunchKernelGGL(kern1, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale);
+                         geom, scale, drop);
       return DPTNAV_OK;
     };
     int rc = DPTNAV_OK;
@@ -1383,11 +1396,23 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
   return run_head_backward<128>(h, br, mix, e1, e2, tb + mt.vid, dcur, B, T, pl.L, S, Tv);
 }
 
+// test helper: the keep-mask (1/0) the attention kernels of (block, path) use under the current dropout options
+int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, float* mask, void* stream) {
+  if (!h || !mask) return DPTNAV_ERR_INVALID;
+  const SeqGeom geom = make_geom(path, B, S, h->cfg.chunk_size);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(geom.nseq, h->cfg.num_heads), dim3(256), 0, (hipStream_t)stream, mask, geom,
+                     h->cfg.num_heads, h->drop_cfg(block, path, true));
+  LAUNCH_CHECK(h, "dropout mask");
+  return DPTNAV_OK;
+}
+
 // ---- tuning / diagnostic knobs ----------------------------------------------------------------------
 int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   if (!h || !key) return DPTNAV_ERR_INVALID;
   const std::string k(key);
   if (k == "lstm_stamps") h->opt_lstm_stamps = value != 0;
+  else if (k == "dropout_ppm" && value >= 0 && value < 1000000) h->opt_dropout_ppm = value;
+  else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;

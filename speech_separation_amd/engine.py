@@ -218,6 +218,16 @@ class DptnEngine:
             self._raise(rc, "dptnav_train_path_backward")
         return dx
 
+    def dropout_mask(self, block: int, path: int, B: int, S: int) -> torch.Tensor:
+        """(nseq, heads, len, len) keep-mask of path (block, path) under the current dropout options (test helper)."""
+        K = self.cfg.chunk_size
+        nseq, ln = (B * S, K) if path == 0 else (B * K, S)
+        m = torch.empty(nseq, self.cfg.num_heads, ln, ln, device=self.device)
+        rc = self.lib.dptnav_dropout_mask(self._h, block, path, B, S, m.data_ptr(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_dropout_mask")
+        return m
+
     # ------------------------------------------------------------------ training step, whole model
     def train_forward(self, mix, e1=None, e2=None):
         """Forward that records the tape; returns (s1_pred, s2_pred, tape)."""

@@ -79,8 +79,14 @@ class _SeparateFn(torch.autograd.Function):
         eng = module._get_engine(mix.device)
         if getattr(eng, "_grads", None) is None:
             eng.bind_grads()
+        # train-mode attention dropout (dptn.py:16-21): a fresh seed per step, the same one for this step's backward
+        ppm = int(round(module.cfg.dropout * 1e6)) if module.training else 0
+        module._drop_step = getattr(module, "_drop_step", 0) + 1
+        seed = (torch.initial_seed() * 2654435761 + module._drop_step * 40503) & 0x7FFFFFFF
+        eng.set_option("dropout_ppm", ppm)
+        eng.set_option("dropout_seed", seed)
         s1, s2, tape = eng.train_forward(mix, e1, e2)
-        ctx.module, ctx.tape, ctx.inputs = module, tape, (mix, e1, e2)
+        ctx.module, ctx.tape, ctx.inputs, ctx.drop = module, tape, (mix, e1, e2), (ppm, seed)
         return s1, s2
 
     @staticmethod
@@ -88,6 +94,8 @@ class _SeparateFn(torch.autograd.Function):
         eng = ctx.module._engine
         mix, e1, e2 = ctx.inputs
         zeros = lambda g: torch.zeros_like(mix) if g is None else g.contiguous()
+        eng.set_option("dropout_ppm", ctx.drop[0])
+        eng.set_option("dropout_seed", ctx.drop[1])
         eng.train_backward(mix, e1, e2, zeros(d_s1), zeros(d_s2), ctx.tape)
         ctx.tape = None
         # the library's gradient buffers are reused by the next step: hand autograd its own copies
@@ -135,10 +143,6 @@ class _DPTNBase(nn.Module):
             if self.cfg.arch != "dptn" or self.cfg.num_features != 128 or not self.cfg.bidir:
                 raise NotImplementedError("the training step (backward kernels) is built for the DPTN architecture with "
                                           "num_features=128, bidir=True (BASELINE config 4); use torch.no_grad() here")
-            if self.training and self.cfg.dropout != 0.0:
-                raise NotImplementedError(
-                    "train-mode attention dropout (dptn.py:16-21) is not implemented in libdptnav: construct the model "
-                    "with dropout=0.0 (a legal constructor argument, SURVEY.md Appendix B) or call model.eval()")
             s1, s2 = _SeparateFn.apply(self, mix.contiguous(), None if e1 is None else e1.contiguous(),
                                        None if e2 is None else e2.contiguous(), *self.parameters())
             return {"s1_pred": s1, "s2_pred": s2}

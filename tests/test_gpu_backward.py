@@ -160,3 +160,60 @@ def test_training_steps_match_stock_pytorch(dev):
         assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(b["loss"])), (ours, theirs)
         assert abs(a["grad_norm"] - b["grad_norm"]) < 1e-3 * b["grad_norm"], (ours, theirs)
     assert ours[2]["loss"] < ours[0]["loss"]          # and the loss goes down
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_dropout_forward_and_backward_match_autograd_with_the_same_mask(dev, path):
+    """Train-mode attention dropout: the kernels' counter-based keep-mask is materialised (dptnav_dropout_mask) and fed to
+    an explicit-formula torch implementation of the path; outputs, dx and all parameter gradients must agree."""
+    import torch.nn.functional as F
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1, "dropout": 0.1})
+    sd = synthetic_state_dict(cfg, seed=9)
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(sd, dev))
+    grads = eng.bind_grads()
+    eng.set_option("dropout_ppm", 100000)
+    eng.set_option("dropout_seed", 12345)
+    B, S, K, N, H, heads = 2, 3, cfg.chunk_size, cfg.num_features, cfg.hidden_dim, cfg.num_heads
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((B, S, K, N)).astype(np.float32)
+    dy = rng.standard_normal((B, S, K, N)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev)
+    y, tape = eng.train_path_forward(0, path, xt)
+    dx = eng.train_path_backward(0, path, xt, torch.from_numpy(dy).to(dev), tape)
+    mask = eng.dropout_mask(0, path, B, S).cpu().double()
+    torch.cuda.synchronize()
+    keep = float(mask.mean())
+    assert 0.88 < keep < 0.92, keep                       # p = 0.1
+    eng.set_option("dropout_seed", 54321)
+    assert not torch.equal(eng.dropout_mask(0, path, B, S).cpu().double(), mask)   # the seed matters
+
+    name = "intra_chunk_block" if path == 0 else "inter_chunk_block"
+    pre = f"dprnn.model.0.{name}."
+    P = {k[len(pre):]: torch.from_numpy(v).double().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+    rnn = torch.nn.LSTM(N, H, bidirectional=True, batch_first=True).double()
+    rnn.load_state_dict({k[4:]: v.detach() for k, v in P.items() if k.startswith("rnn.")})
+    xs = torch.from_numpy(x).double()
+    seqs = (xs.reshape(B * S, K, N) if path == 0 else xs.transpose(1, 2).reshape(B * K, S, N)).requires_grad_(True)
+    R, Ls = seqs.shape[0], seqs.shape[1]
+    dh = N // heads
+    with torch.enable_grad():
+        qkv = F.linear(seqs, P["mha.in_proj_weight"], P["mha.in_proj_bias"])
+        q, k, v = (t.reshape(R, Ls, heads, dh).transpose(1, 2) for t in qkv.split(N, -1))
+        prob = torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) * mask / 0.9
+        att = (prob @ v).transpose(1, 2).reshape(R, Ls, N)
+        y1 = F.layer_norm(F.linear(att, P["mha.out_proj.weight"], P["mha.out_proj.bias"]) + seqs, (N,), P["ln1.weight"], P["ln1.bias"])
+        z = F.linear(F.relu(rnn(y1)[0]), P["ffn.1.weight"], P["ffn.1.bias"]) + y1
+        out = F.layer_norm(z, (N,), P["ln2.weight"], P["ln2.bias"])
+        dys = torch.from_numpy(dy).double()
+        out.backward(dys.reshape(B * S, K, N) if path == 0 else dys.transpose(1, 2).reshape(B * K, S, N))
+
+    def back(a):
+        return a.reshape(B, S, K, N) if path == 0 else a.reshape(B, K, S, N).transpose(1, 2)
+    assert O.agreement_db(y.cpu().numpy(), back(out.detach()).numpy()) > 80
+    assert O.agreement_db(dx.cpu().numpy(), back(seqs.grad).numpy()) > 70
+    want = {k: v.grad for k, v in P.items() if not k.startswith("rnn.")}
+    want.update({"rnn." + k: v.grad for k, v in rnn.named_parameters()})
+    for leaf, gref in want.items():
+        assert O.agreement_db(grads[pre + leaf].cpu().numpy(), gref.numpy()) > 65, leaf
