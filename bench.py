@@ -106,7 +106,18 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
         best = max(best, rate)
         if time.perf_counter() - t_start > seconds_budget:
             break
+    # BASELINE configs[0]: the reference's own CPU-runnable case (Conv-TasNet, batch 4) -- an extra CPU datum
+    from oracle import convtasnet_stock as CT
+    csd = {k: torch.from_numpy(v) for k, v in CT.synthetic_convtasnet_weights(0).items()}
+    cmix = torch.from_numpy(synthetic_inputs(cfg, B=4, T=T_SAMPLES, Tv=50, seed=5)["mix"])
+    CT.forward(csd, cmix)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        CT.forward(csd, cmix)
+    conv_rate = 4 * 3 / (time.perf_counter() - t0)
     return {"value": round(best, 4), "unit": "mixtures/sec", "cores": cores, "kind": "port",
+            "configs0_convtasnet_cpu": {"value": round(conv_rate, 3), "unit": "mixtures/sec", "batch": 4,
+                                        "note": "oracle/convtasnet_stock.py = src/model/convtasnet.py with stock PyTorch ops"},
             "sample": "oracle/torch_stock.py (stock PyTorch CPU ops, fp32, eval/no_grad), T=32000, 1 warm-up + "
                       + "; ".join(parts) + "; max over B reported"}
 

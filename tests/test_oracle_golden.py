@@ -103,3 +103,20 @@ def test_stock_torch_composition_real_sizes(golden):
     out = StockDPTN(cfg, sd)(**{k: torch.from_numpy(v) for k, v in inp.items()})
     for k in ("s1_pred", "s2_pred"):
         assert O.agreement_db(out[k].numpy(), z["tap." + k]) > 100, k
+
+
+def test_convtasnet_stock_composition_matches_reference():
+    """BASELINE configs[0] (the reference's CPU-only case): oracle/convtasnet_stock.py vs the reference's ConvTasNet."""
+    import os
+    import torch
+    from oracle import convtasnet_stock as CT
+    from tests.conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "convtasnet.npz"))
+    sd = CT.synthetic_convtasnet_weights(seed=0)
+    assert weights_digest(sd) == str(z["digest"])
+    assert sum(int(np.prod(s)) for _, s in CT.convtasnet_spec()) == 5_066_929          # SURVEY.md section 6
+    from speech_separation_amd.spec import DPTN_AUDIO
+    mix = synthetic_inputs(DPTN_AUDIO, B=2, T=4000, seed=21)["mix"]
+    out = CT.forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(mix))
+    for k in ("s1_pred", "s2_pred"):
+        assert out[k].shape == (2, 4000) and O.agreement_db(out[k].numpy(), z[k]) > 100

@@ -169,5 +169,19 @@ def main():
         print(name, "loss", extra["pit_loss"], "rms", float(np.sqrt((taps['s1_pred'] ** 2).mean())))
 
 
+    # ---- 3. Conv-TasNet (BASELINE configs[0], CPU-only reference case): outputs for seeded weights ----
+    from oracle.convtasnet_stock import convtasnet_spec, synthetic_convtasnet_weights
+    ct = importlib.import_module("src.model.convtasnet").ConvTasNet().eval()
+    assert [(k, tuple(v.shape)) for k, v in ct.state_dict().items()] == convtasnet_spec(), "ConvTasNet spec drifted"
+    wsd = synthetic_convtasnet_weights(seed=0)
+    ct.load_state_dict({k: torch.from_numpy(v) for k, v in wsd.items()}, strict=True)
+    mixc = synthetic_inputs(DPTN_AUDIO, B=2, T=4000, seed=21)["mix"]
+    with torch.no_grad():
+        outc = ct(mix=torch.from_numpy(mixc))
+    np.savez_compressed(os.path.join(OUT, "convtasnet.npz"), digest=np.array(weights_digest(wsd)),
+                        s1_pred=outc["s1_pred"].numpy(), s2_pred=outc["s2_pred"].numpy())
+    print("convtasnet", outc["s1_pred"].shape, float(outc["s1_pred"].abs().mean()))
+
+
 if __name__ == "__main__":
     main()
