@@ -261,6 +261,15 @@ def main():
                    "launch_ms": round(iso_ms, 4), "achieved": round(iso_tflops, 3),
                    "frac": round(iso_tflops / PEAK_F32_MFMA_TFLOPS, 4)}
         kernels = {k: round(v[0] / psteps, 4) for k, v in prof.items()}
+        # which recurrence kernel those launches were (run_path in dptnav.hip: 16-sequence tiles when they fit the
+        # chip in one round, i.e. for half-batch launches; 32-sequence tiles otherwise)
+        b_launch = B * 2 * cfg.num_blocks / launches_per_step
+        ndir = 2 if cfg.bidir else 1
+        fits16 = all(-(-int(b_launch * n) // 16) * d <= torch.cuda.get_device_properties(dev).multi_processor_count
+                     for n, d in ((S, 2), (K, ndir)))
+        lstm_kernel = "lstm16_kernel" if fits16 else "lstm_recurrence_kernel"
+        if iso is not None:
+            iso["kernel"] = "lstm_recurrence_kernel"
         value = env.world * B * args.steps / elapsed
         line = {
             "metric": "mixtures/sec (2-spk, 4 s @ 8 kHz) DPTN-AV forward" if args.config == "dptn_av"
@@ -271,7 +280,7 @@ def main():
             "config": {"workload": f"{workload}, batch={B} per GPU, T={T}, random-init weights (numpy seed 0)",
                        "batch_per_gpu": B, "samples": T, "tokens_per_mixture": S * K,
                        "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "lstm_recurrence_kernel", "achieved": round(achieved, 3),
+            "roofline": {"bound": "mfma", "kernel": lstm_kernel, "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": measured_traffic(M * 2 * cfg.num_blocks / launches_per_step),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_lstm_hbm_traffic.json)",

@@ -180,6 +180,8 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 hash of (seed, block, path, query token, head, key position): reproducible, identical in forward and
  *                 backward, but NOT PyTorch's Philox stream (parity with the reference is statistical only).  The caller
  *                 changes the seed every step and sets the same seed for the backward of that step.
+ *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
+ *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
  *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
 int dptnav_set_option(dptnav_handle h, const char* key, int value);

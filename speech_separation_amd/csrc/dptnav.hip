@@ -15,6 +15,7 @@
 #include "gemm_ws.h"
 #include "headtail.h"
 #include "lstm.h"
+#include "lstm16.h"
 #include "sisnr.h"
 #include "backward.h"
 #include "backward_ends.h"
@@ -71,6 +72,7 @@ struct dptnav_ctx {
   bool prof_on = false;
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
+  bool opt_lstm16 = true;
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
   DropCfg drop_cfg(int block, int path, bool train) const {
@@ -425,23 +427,43 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
     if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
   }
+  // K4/K5 tile height: 32 sequences per workgroup, or 16 when that still fits the chip in one round (half-batch
+  // launches of dptnav_forward): same CU-time, half the serial time of the recurrence (lstm16.h)
+  const int nst16 = (geom.nseq + 15) / 16;
+  const bool use16 = !pb.train && !c->opt_lstm_stamps && c->opt_lstm16 && nst16 * w.ndir <= c->num_cus;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{lstm_in, N, geom};
-    EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
-    if (int rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]))
-      return rc;
+    int rc;
+    if (use16) {
+      EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
+      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+    } else {
+      EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
+      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+    }
+    if (rc) return rc;
   }
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
-  {
+  if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
+    return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
+  if (use16) {
+    static bool ready = false;
+    if (!ready) {
+      if (int rc = set_lds(c, lstm16_kernel, L16_LDS_BYTES, "lstm16")) return rc;
+      ready = true;
+    }
+    ProfScope ps(c, CAT_LSTM, st);
+    hipLaunchKernelGGL(lstm16_kernel, dim3(nst16, w.ndir), dim3(256), L16_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
+                       w.ndir * LSTM_H, (int)M, geom, nst16, c->cfg.arch == 0 ? 1 : 0);
+    LAUNCH_CHECK(c, "lstm16");
+  } else {
     auto kern = pb.train ? lstm_recurrence_kernel<false, true>
                          : (c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>);
     if (int rc = set_lds(c, kern, LSTM_LDS_BYTES, "lstm")) return rc;
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
-    if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
-      return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
     ProfScope ps(c, CAT_LSTM, st);
     hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
                        w.ndir * LSTM_H, (int)M, geom, stamps, (c->cfg.arch == 0 && !pb.train) ? 1 : 0, pb.gates, pb.cst);
@@ -1414,6 +1436,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_ppm" && value >= 0 && value < 1000000) h->opt_dropout_ppm = value;
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
+  else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }

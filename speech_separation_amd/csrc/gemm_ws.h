@@ -367,6 +367,33 @@ struct EpiLstmPre {
 };
 
 
+// Same, in the 16-sequence-tile layout of lstm16.h: PRE16[d][st16][t][cb32][lane64][4].  Accumulator registers 4q..4q+3
+// of lane (c,hh) are rows 8q+4hh+i of the 32-sequence GEMM tile -> 16-sequence tile 2*st + (q>>1), ks = 2(q&1)+hh;
+// column c -> 16-column block 2cb + (c>>4), i16 = c&15.
+struct EpiLstmPre16 {
+  static constexpr bool DIRECT = true;
+  static constexpr bool HAS_FINISH = false;
+  float* pre;
+  const float* b_ih[2];
+  const float* b_hh[2];
+  SeqGeom g;
+  int nst16;
+  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
+    const int st = tile / g.len, t = tile - st * g.len;
+    const int j = cb * 32 + c;
+    const float bias = b_ih[d][j] + b_hh[d][j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int st16 = 2 * st + (q >> 1);
+      if (st16 >= nst16) continue;   // a 16-sequence tile made of padding only
+      float* base = pre + (((int64_t)d * nst16 + st16) * g.len + t) * (int64_t)(512 * 16) + (2 * cb + (c >> 4)) * 256 +
+                    ((2 * (q & 1) + hh) * 16 + (c & 15)) * 4;
+      *reinterpret_cast<float4*>(base) =
+          make_float4(acc[4 * q + 0] + bias, acc[4 * q + 1] + bias, acc[4 * q + 2] + bias, acc[4 * q + 3] + bias);
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // training-step hooks (backward pass)
 // ------------------------------------------------------------------------------------------------
