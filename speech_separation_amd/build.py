@@ -12,32 +12,56 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdptnav.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["dptnav.hip"]
-HEADERS = ["common.h", "gemm_ws.h", "attention.h", "lstm.h", "headtail.h", os.path.join("..", "..", "include", "dptnav.h")]
+# translation units and their extra flags.  lstm16.hip: MFMA accumulators in architectural VGPRs so that the 256 W_hh
+# fragments own the AGPRs and the step loop carries no v_accvgpr moves (see the file's header).
+SOURCES = {"dptnav.hip": [], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def _headers():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "dptnav.h")]
 
 
 def _stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in list(SOURCES) + _headers())
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_lib(force: bool = False, verbose: bool = False, out: str = OUT, extra_flags=()) -> str:
+    """Compile csrc/dptnav.hip.  `out` / `extra_flags` exist for A/B experiments (tools/): the product is OUT."""
+    if out == OUT and not force and not _stale():
         return OUT
     log = os.path.join(HERE, "csrc", "build_resource_usage.log")
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-Rpass-analysis=kernel-resource-usage", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    objdir = os.path.join(HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    tag = os.path.splitext(os.path.basename(out))[0]
+    base = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Rpass-analysis=kernel-resource-usage"] + list(extra_flags)
+    jobs = []
+    for src, flags in SOURCES.items():
+        obj = os.path.join(objdir, f"{tag}.{os.path.splitext(src)[0]}.o")
+        cmd = base + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    errs, objs = [], []
+    for obj, proc in jobs:   # the units compile side by side
+        _, err = proc.communicate()
+        errs.append(err)
+        objs.append(obj)
+        if proc.returncode != 0:
+            sys.stderr.write(err[-4000:])
+            with open(log, "w") as f:
+                f.write("".join(errs))
+            raise RuntimeError(f"hipcc failed ({proc.returncode}) on {obj}; full log in {log}")
     with open(log, "w") as f:
-        f.write(r.stderr)
+        f.write("".join(errs))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-4000:])
-        raise RuntimeError(f"hipcc failed ({r.returncode}); full log in {log}")
-    return OUT
+        raise RuntimeError(f"link failed ({r.returncode})")
+    return out
 
 
 if __name__ == "__main__":

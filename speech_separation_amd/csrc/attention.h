@@ -17,6 +17,11 @@
 #pragma once
 #include "common.h"
 
+// phase stamps for tools/microbench/attn_phases.hip (a diagnostic build defines ATTN_STAMP; the product build does not)
+#ifndef ATTN_STAMP
+#define ATTN_STAMP(i)
+#endif
+
 template <int DH>
 struct AttnShape {
   static constexpr int LDK = DH + 4;  // K rows: conflict-free ds_read_b128
@@ -26,15 +31,17 @@ struct AttnShape {
 
 template <int DH, int NKB>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_kernel(const float* __restrict__ qkv,
-                                                              float* __restrict__ out, int N, SeqGeom g,
+                                                              float* __restrict__ out, int N, int heads, SeqGeom g,
                                                               float scale_log2e, DropCfg drop) {
   using Sh = AttnShape<DH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                        // [NKB*32][LDK]
   float* Vs = smem + NKB * 32 * Sh::LDK;   // [NKB*32][32]
 
+  ATTN_STAMP(0);
   const int tid = threadIdx.x;
   const int qb = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  // sequence-fastest grid order (head-adjacent workgroups measured 1-4 % slower)
   const int seq = blockIdx.x, head = blockIdx.y;
   const int len = g.len;
   const int64_t tok0 = seq_token_base(g, seq);
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     if (DH == 16) *reinterpret_cast<float4*>(&Vs[p * Sh::LDV + 16 + 4 * f]) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
+  ATTN_STAMP(1);
 
   // ---- S^T = K Q^T ------------------------------------------------------------------------------
   f32x16 s[NKB];
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     }
   }
 
+  ATTN_STAMP(2);
   // ---- softmax over keys (per query = per lane column); only the last key block can hold padding ----
 #pragma unroll
   for (int r = 0; r < 16; ++r)
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   sum += __shfl_xor(sum, 32);
   const float inv = fast_rcp(sum);
   if (drop.thresh != 0u) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
-    const uint32_t qh = (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)gridDim.y + (uint32_t)head;
+    const uint32_t qh = (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)heads + (uint32_t)head;
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb)
 #pragma unroll
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         s[rb][r] = drop_rand(drop.seed, qh, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
   }
 
+  ATTN_STAMP(3);
   // ---- O = P V: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them ----
   f32x16 o = zero16();
   const float* vcol = Vs + (4 * hh) * Sh::LDV + c;
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     for (int r = 0; r < 16; ++r) o = mfma32(s[rb][r], vv[r], o);
   }
 
+  ATTN_STAMP(4);
   // ---- normalise and store: reg r of lane (c,hh) is O[query ROW32(r,hh)][d = c] -----------------
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -150,4 +161,5 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     const int p = qb * 32 + ql;
     if (p < len && c < DH) out[(tok0 + (int64_t)p * tstride) * N + head * DH + c] = o[r] * iv;
   }
+  ATTN_STAMP(5);
 }

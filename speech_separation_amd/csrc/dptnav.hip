@@ -73,6 +73,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  int opt_lstm_diag = 0;
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
   DropCfg drop_cfg(int block, int path, bool train) const {
@@ -333,7 +334,7 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
   }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
-  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, g, scale, drop);
+  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, heads, g, scale, drop);
   LAUNCH_CHECK(c, "attention");
   return DPTNAV_OK;
 }
@@ -430,7 +431,9 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K4/K5 tile height: 32 sequences per workgroup, or 16 when that still fits the chip in one round (half-batch
   // launches of dptnav_forward): same CU-time, half the serial time of the recurrence (lstm16.h)
   const int nst16 = (geom.nseq + 15) / 16;
-  const bool use16 = !pb.train && !c->opt_lstm_stamps && c->opt_lstm16 && nst16 * w.ndir <= c->num_cus;
+  // (lstm16 addresses hc with 32-bit byte offsets: rows [0, M + S*K) x ldh floats)
+  const bool use16 = !pb.train && c->opt_lstm16 && nst16 * w.ndir <= c->num_cus &&
+                     (uint64_t)(M + (int64_t)geom.S * geom.K) * (uint64_t)(w.ndir * LSTM_H) * 4u < (1ull << 32);
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{lstm_in, N, geom};
@@ -449,15 +452,14 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
   if (use16) {
-    static bool ready = false;
-    if (!ready) {
-      if (int rc = set_lds(c, lstm16_kernel, L16_LDS_BYTES, "lstm16")) return rc;
-      ready = true;
-    }
+    // lstm_stamps: diagnostic builds; lstm_diag > 0 are timing-only ablations (wrong results), see lstm16.hip
+    const int variant = c->opt_lstm_stamps ? 1 + c->opt_lstm_diag : 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);   // room: nst16 <= 2 nst
     ProfScope ps(c, CAT_LSTM, st);
-    hipLaunchKernelGGL(lstm16_kernel, dim3(nst16, w.ndir), dim3(256), L16_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                       w.ndir * LSTM_H, (int)M, geom, nst16, c->cfg.arch == 0 ? 1 : 0);
-    LAUNCH_CHECK(c, "lstm16");
+    // DPTN feeds ffn = ReLU -> Linear (dptn.py:31); DPRNN feeds fc directly
+    const int rc = lstm16_launch(variant, c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
+                                 w.ndir * LSTM_H, (int)M, geom, stamps);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16: %s", hipGetErrorString((hipError_t)rc));
   } else {
     auto kern = pb.train ? lstm_recurrence_kernel<false, true>
                          : (c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>);
@@ -1437,6 +1439,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
+  else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }

@@ -18,6 +18,7 @@
 //                          (so LayerNorm statistics are a sub-wave shuffle reduction).
 #pragma once
 #include "common.h"
+#include "lstm16.h"
 
 template <int KIN, int NT, int WR, int WC>
 struct GemmShape {
@@ -367,9 +368,10 @@ struct EpiLstmPre {
 };
 
 
-// Same, in the 16-sequence-tile layout of lstm16.h: PRE16[d][st16][t][cb32][lane64][4].  Accumulator registers 4q..4q+3
-// of lane (c,hh) are rows 8q+4hh+i of the 32-sequence GEMM tile -> 16-sequence tile 2*st + (q>>1), ks = 2(q&1)+hh;
-// column c -> 16-column block 2cb + (c>>4), i16 = c&15.
+// Same, in the 16-sequence-tile layout of lstm16.h: PRE16[d][st16][t][w][b][lane64][4], pre-scaled per gate.
+// Accumulator registers 4q..4q+3 of lane (c,hh) are rows 8q+4hh+i of the 32-sequence GEMM tile -> 16-sequence tile
+// 2*st + (q>>1), ks = 2(q&1)+hh.  Column block cb (32 of the direction's 512 gate columns): gate = cb >> 2,
+// wave w = cb & 3 (hidden units [32w, 32w+32)), half = c >> 4, i16 = c & 15.
 struct EpiLstmPre16 {
   static constexpr bool DIRECT = true;
   static constexpr bool HAS_FINISH = false;
@@ -381,15 +383,19 @@ struct EpiLstmPre16 {
   DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
     const int st = tile / g.len, t = tile - st * g.len;
     const int j = cb * 32 + c;
-    const float bias = b_ih[d][j] + b_hh[d][j];
+    const int gate = cb >> 2;
+    // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm16.hip evaluates the activations
+    // without a multiply
+    const float gs = l16_gate_scale(gate);
+    const float bias = (b_ih[d][j] + b_hh[d][j]) * gs;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int st16 = 2 * st + (q >> 1);
       if (st16 >= nst16) continue;   // a 16-sequence tile made of padding only
-      float* base = pre + (((int64_t)d * nst16 + st16) * g.len + t) * (int64_t)(512 * 16) + (2 * cb + (c >> 4)) * 256 +
+      float* base = pre + pre16_tile_offset(d, st16, t, nst16, g.len) + (cb & 3) * 2048 + (2 * gate + (c >> 4)) * 256 +
                     ((2 * (q & 1) + hh) * 16 + (c & 15)) * 4;
-      *reinterpret_cast<float4*>(base) =
-          make_float4(acc[4 * q + 0] + bias, acc[4 * q + 1] + bias, acc[4 * q + 2] + bias, acc[4 * q + 3] + bias);
+      *reinterpret_cast<float4*>(base) = make_float4(fmaf(acc[4 * q + 0], gs, bias), fmaf(acc[4 * q + 1], gs, bias),
+                                                     fmaf(acc[4 * q + 2], gs, bias), fmaf(acc[4 * q + 3], gs, bias));
     }
   }
 };

@@ -15,17 +15,23 @@ dev = torch.device("cuda:0")
 cfg = DPTN_AV
 eng = DptnEngine(cfg, dev)
 eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
-B, T = 16, 32000
+# usage: lstm_stamps.py [B] [tile]   (tile 16 needs ceil(B*S/16)*2 <= CUs, i.e. B <= 8 at T = 32000)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+T = 32000
 S = eng.chunks(T)
+eng.set_option("lstm16", 1 if tile == 16 else 0)
+if len(sys.argv) > 3:
+    eng.set_option("lstm_diag", int(sys.argv[3]))   # timing-only ablations (results are wrong)
 x = torch.randn(B, S, cfg.chunk_size, cfg.num_features, device=dev)
 eng.stage_path(0, 0, x)
 eng.set_option("lstm_stamps", 1)
 eng.stage_path(0, 0, x)
 torch.cuda.synchronize()
 raw = eng.tap("lstm_stamps", B, eng._path_T(S)).view(torch.int64).cpu().numpy()
-nst = (B * S + 31) // 32
+nst = (B * S + tile - 1) // tile
 a = raw[: 2 * nst * 4 * 4].reshape(2, nst, 4, 4).astype(np.float64) / cfg.chunk_size
-print("cycles per step (mean over waves):  acc-init %.0f   mfma %.0f   cell %.0f   barrier %.0f   total %.0f"
+print(f"B={B} tile={tile}");print("cycles per step (mean over waves):  acc-init %.0f   mfma %.0f   cell %.0f   barrier %.0f   total %.0f"
       % (*a.mean((0, 1, 2)), a.sum(-1).mean()))
 print("per wave (tile 0, dir 0):", a[0, 0].round(0).tolist())
 print("max-over-waves total:", a.sum(-1).max(), " min:", a.sum(-1).min())
