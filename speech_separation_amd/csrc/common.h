@@ -38,6 +38,27 @@ DEV float fast_sigmoid(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408
 // 2/(1+e^-2x) - 1 : saturates correctly to +-1 (no inf/inf)
 DEV float fast_tanh(float x) { return fmaf(2.0f, fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * x)), -1.0f); }
 
+// LSTM cell update for TWO accumulator slots at once, from PRE-SCALED gate pre-activations (scale -log2e for i, f, o and
+// -2 log2e for g: sigmoid = rcp(1 + exp2(a)), tanh = 2 rcp(1 + exp2(a)) - 1).  Written on 2-vectors so that the
+// non-transcendental half of the work issues as packed fp32 instructions (v_pk_add/mul/fma_f32: two slots per issue).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEV f32x2 exp2_2(f32x2 a) { return (f32x2){fast_exp2(a.x), fast_exp2(a.y)}; }
+DEV f32x2 rcp_2(f32x2 a) { return (f32x2){fast_rcp(a.x), fast_rcp(a.y)}; }
+struct LstmCell2 {
+  f32x2 i, f, g, o, c, h;
+};
+DEV LstmCell2 lstm_cell2(f32x2 ai, f32x2 af, f32x2 ag, f32x2 ao, f32x2 c_prev) {
+  LstmCell2 r;
+  r.i = rcp_2(1.0f + exp2_2(ai));
+  r.f = rcp_2(1.0f + exp2_2(af));
+  r.g = 2.0f * rcp_2(1.0f + exp2_2(ag)) - 1.0f;
+  r.o = rcp_2(1.0f + exp2_2(ao));
+  r.c = r.f * c_prev + r.i * r.g;
+  const f32x2 th = 2.0f * rcp_2(1.0f + exp2_2(r.c * -2.8853900817779268f)) - 1.0f;
+  r.h = r.o * th;
+  return r;
+}
+
 // Sum over groups of 16 or 32 adjacent lanes, result in every lane, entirely on the VALU (DPP + one
 // v_permlane16_swap): __shfl_xor lowers to ds_bpermute_b32, whose LDS-crossbar round trip (~100 cycles, waited
 // for with lgkmcnt(0)) dominated the LayerNorm epilogues.

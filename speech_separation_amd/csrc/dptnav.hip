@@ -461,15 +461,14 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
                                  w.ndir * LSTM_H, (int)M, geom, stamps);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16: %s", hipGetErrorString((hipError_t)rc));
   } else {
-    auto kern = pb.train ? lstm_recurrence_kernel<false, true>
-                         : (c->opt_lstm_stamps ? lstm_recurrence_kernel<true> : lstm_recurrence_kernel<false>);
-    if (int rc = set_lds(c, kern, LSTM_LDS_BYTES, "lstm")) return rc;
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
     ProfScope ps(c, CAT_LSTM, st);
-    hipLaunchKernelGGL(kern, dim3(geom.nst, w.ndir), dim3(256), LSTM_LDS_BYTES, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                       w.ndir * LSTM_H, (int)M, geom, stamps, (c->cfg.arch == 0 && !pb.train) ? 1 : 0, pb.gates, pb.cst);
-    LAUNCH_CHECK(c, "lstm");
+    // DPTN inference stores ReLU(h) (ffn = ReLU -> Linear, dptn.py:31); training keeps raw h for the tape, DPRNN
+    // feeds fc directly
+    const int rc = lstm32_launch(c->opt_lstm_stamps && !pb.train, pb.train, c->cfg.arch == 0 && !pb.train, geom.nst, w.ndir,
+                                 st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom, stamps, pb.gates, pb.cst);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm: %s", hipGetErrorString((hipError_t)rc));
   }
   if (run.lstm_record && hipEventRecord(run.lstm_record, st) != hipSuccess)
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger record");

@@ -18,6 +18,7 @@
 //                          (so LayerNorm statistics are a sub-wave shuffle reduction).
 #pragma once
 #include "common.h"
+#include "lstm.h"
 #include "lstm16.h"
 
 template <int KIN, int NT, int WR, int WC>
@@ -353,15 +354,18 @@ struct EpiLstmPre {
   DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
     const int st = tile / g.len, t = tile - st * g.len;
     const int j = cb * 32 + c;
-    const float bias = b_ih[d][j] + b_hh[d][j];
+    // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm.hip evaluates the activations
+    // without a multiply (cb >> 2 is the gate; the bias add became an fma)
+    const float gs = lstm_gate_scale(cb >> 2);
+    const float bias = (b_ih[d][j] + b_hh[d][j]) * gs;
     float* base = pre + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)cb * 1024 + hh * 128 + c * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float4 v;
-      v.x = acc[4 * q + 0] + bias;
-      v.y = acc[4 * q + 1] + bias;
-      v.z = acc[4 * q + 2] + bias;
-      v.w = acc[4 * q + 3] + bias;
+      v.x = fmaf(acc[4 * q + 0], gs, bias);
+      v.y = fmaf(acc[4 * q + 1], gs, bias);
+      v.z = fmaf(acc[4 * q + 2], gs, bias);
+      v.w = fmaf(acc[4 * q + 3], gs, bias);
       *reinterpret_cast<float4*>(base + q * 256) = v;
     }
   }

@@ -39,9 +39,6 @@ DEV void glds16_off(const float* gsrc, float* lds_wave_base) {
 // that comes from memory costs a canonicalising v_max_f32 first
 DEV float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
-// activations of PRE-SCALED arguments
-DEV float l16_sigmoid(float a) { return fast_rcp(1.0f + fast_exp2(a)); }
-DEV float l16_tanh(float a) { return fmaf(2.0f, fast_rcp(1.0f + fast_exp2(a)), -1.0f); }
 
 // STAMP: diagnostic build, per-wave s_memtime sums of [init, MFMA block (with the interleaved cell update), exposed
 // cell update, barrier] go to stamps[dir][tile][wave][4].  DIAG (timing-only ablations, results are wrong):
@@ -111,6 +108,15 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
     glds16_off<2048>(p + 1024, ps_wave + 1024);
     glds16_off<3072>(p + 1024, ps_wave + 1024);
   };
+  auto issue_pre_piece = [&](const float* p, int piece) {   // compile-time after unrolling
+    const int hi = piece >> 2;
+    switch (piece & 3) {
+      case 0: glds16_off<0>(p + hi * 1024, ps_wave + hi * 1024); break;
+      case 1: glds16_off<1024>(p + hi * 1024, ps_wave + hi * 1024); break;
+      case 2: glds16_off<2048>(p + hi * 1024, ps_wave + hi * 1024); break;
+      default: glds16_off<3072>(p + hi * 1024, ps_wave + hi * 1024); break;
+    }
+  };
   issue_pre(pre_lane + (int64_t)t0 * L16_TILE_FLOATS);
   __syncthreads();
 
@@ -148,6 +154,9 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
     // accumulators in architectural VGPRs (the cell update reads them with plain VALU instructions)
 #pragma unroll
     for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
+    // (without this pin the allocator tries the full AGPR half for these load results and spills them)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hs[j].x), "+v"(hs[j].y), "+v"(hs[j].z), "+v"(hs[j].w));
     if (STAMP) c1 = __builtin_amdgcn_s_memtime();
 
     // branch-free: the last step re-requests its own tile; step 0 stores the zeros of h_{-1} at position t0 without
@@ -159,6 +168,28 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
       for (int j = 0; j < 2; ++j)
         hs[j] = make_float4(relu1(hs[j].x), relu1(hs[j].y), relu1(hs[j].z), relu1(hs[j].w));
     }
+
+    // cell update of unit half hf (lane-local, two accumulator slots per call) + publish h_t
+    auto cell_half = [&](int hf) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        float h0, h1;
+        if (DIAG & 8) {   // timing-only ablation: no transcendentals
+          h0 = (acc[hf][r] + acc[2 + hf][r] + acc[4 + hf][r] + acc[6 + hf][r]) * 1e-3f;
+          h1 = (acc[hf][r + 1] + acc[2 + hf][r + 1] + acc[4 + hf][r + 1] + acc[6 + hf][r + 1]) * 1e-3f;
+        } else {
+          const LstmCell2 u = lstm_cell2((f32x2){acc[hf][r], acc[hf][r + 1]}, (f32x2){acc[2 + hf][r], acc[2 + hf][r + 1]},
+                                         (f32x2){acc[4 + hf][r], acc[4 + hf][r + 1]},
+                                         (f32x2){acc[6 + hf][r], acc[6 + hf][r + 1]}, (f32x2){cst[hf][r], cst[hf][r + 1]});
+          cst[hf][r] = u.c.x;
+          cst[hf][r + 1] = u.c.y;
+          h0 = u.h.x;
+          h1 = u.h.y;
+        }
+        hnext[(4 * ks + r) * L16_LDH + 32 * w + 16 * hf + i16] = h0;
+        hnext[(4 * ks + r + 1) * L16_LDH + 32 * w + 16 * hf + i16] = h1;
+      }
+    };
 
     // h_{t-1} W_hh^T.  Unit half hf = the wave's units [32w + 16hf, +16): its four gate blocks finish before the other
     // half starts, so half 0's cell update can be spread between half 1's MFMAs (which keeps its dependent VALU
@@ -173,16 +204,14 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
 #pragma unroll
           for (int gt = 0; gt < 4; ++gt) acc[2 * gt + hf] = mfma16(av[tt], wf[2 * gt + hf][4 * m + tt], acc[2 * gt + hf]);
           const int slot = 4 * m + tt;
-          if (hf == 0 && slot == 0) {
-            if (!(DIAG & 1)) issue_pre(pnext);
+          // one memory instruction per MFMA group (issued back to back they stall the wave on the memory pipeline's
+          // queue): slots 0, 1 the stores of h_{t-1}, slots 2..9 the LDS-DMA requests
+          if (hf == 0 && slot < 2) {
+            if (!(DIAG & 2)) *reinterpret_cast<float4*>(hcb + soff[slot]) = hs[slot];
+            soff[slot] += adv;
             __builtin_amdgcn_sched_barrier(0);
-          } else if (hf == 0 && slot == 1) {
-            if (!(DIAG & 2)) {
-#pragma unroll
-              for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(hcb + soff[j]) = hs[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) soff[j] += adv;
+          } else if (hf == 0 && slot < 10) {
+            if (!(DIAG & 1)) issue_pre_piece(pnext, slot - 2);
             __builtin_amdgcn_sched_barrier(0);
           } else if (hf == 1) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -190,33 +219,13 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
           }
         }
       }
-      if (hf == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ig = (DIAG & 8) ? acc[0][r] : l16_sigmoid(acc[0][r]);
-          const float fg = (DIAG & 8) ? acc[2][r] : l16_sigmoid(acc[2][r]);
-          const float gg = (DIAG & 8) ? acc[4][r] : l16_tanh(acc[4][r]);
-          const float og = (DIAG & 8) ? acc[6][r] : l16_sigmoid(acc[6][r]);
-          const float cn = fmaf(fg, cst[0][r], ig * gg);
-          cst[0][r] = cn;
-          hnext[(4 * ks + r) * L16_LDH + 32 * w + i16] = (DIAG & 8) ? og * 1e-3f + cn * 1e-3f : og * fast_tanh(cn);
-        }
-      }
+      if (hf == 0) cell_half(0);
     }
     if (STAMP) {
       asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::"v"(acc[1][0]), "v"(acc[7][3]));
       c2 = __builtin_amdgcn_s_memtime();
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float ig = (DIAG & 8) ? acc[1][r] : l16_sigmoid(acc[1][r]);
-      const float fg = (DIAG & 8) ? acc[3][r] : l16_sigmoid(acc[3][r]);
-      const float gg = (DIAG & 8) ? acc[5][r] : l16_tanh(acc[5][r]);
-      const float og = (DIAG & 8) ? acc[7][r] : l16_sigmoid(acc[7][r]);
-      const float cn = fmaf(fg, cst[1][r], ig * gg);
-      cst[1][r] = cn;
-      hnext[(4 * ks + r) * L16_LDH + 32 * w + 16 + i16] = (DIAG & 8) ? og * 1e-3f + cn * 1e-3f : og * fast_tanh(cn);
-    }
+    cell_half(1);
     if (step + 1 < g.len) preload_acc();
     if (STAMP) c3 = __builtin_amdgcn_s_memtime();
     __syncthreads();
