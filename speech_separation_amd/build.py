@@ -14,7 +14,8 @@ OUT = os.path.join(HERE, "libdptnav.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # translation units and their extra flags.  lstm.hip / lstm16.hip: MFMA accumulators in architectural VGPRs so that the 256 W_hh
 # fragments own the AGPRs and the step loop carries no v_accvgpr moves (see the file's header).
-SOURCES = {"dptnav.hip": [], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+SOURCES = {"dptnav.hip": [], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "lstm_bptt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _headers():

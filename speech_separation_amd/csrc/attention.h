@@ -131,15 +131,14 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   sum += __shfl_xor(sum, 32);
   const float inv = fast_rcp(sum);
   if (drop.thresh != 0u) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
-    const uint32_t qh = (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)heads + (uint32_t)head;
+    const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)heads + (uint32_t)head);
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        s[rb][r] = drop_rand(drop.seed, qh, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
+        s[rb][r] = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
   }
 
-  ATTN_STAMP(3);
   // ---- O = P V: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them ----
   f32x16 o = zero16();
   const float* vcol = Vs + (4 * hh) * Sh::LDV + c;

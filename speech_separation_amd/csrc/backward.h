@@ -6,6 +6,7 @@
 //                    a fixed order -> bit-reproducible, no float atomics.
 //   colsum_kernel    bias gradients: column sums of dY over the tokens, same slab scheme.
 #pragma once
+#include "lstm_bptt.h"
 #include "common.h"
 #include "gemm_ws.h"
 #include "lstm.h"
@@ -206,123 +207,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// LSTM backward through time (mirror image of lstm_recurrence_kernel)
-// ------------------------------------------------------------------------------------------------
-// One workgroup = one direction x 32 sequences, all steps, walked against the forward order.  Per step:
-//   dh = upstream[t] + recurrent;  do = dh*tanh(c);  dc += dh*o*(1-tanh(c)^2);  di = dc*g;  dg = dc*i;  df = dc*c_prev;
-//   dP = (di*i(1-i), df*f(1-f), dg*(1-g^2), do*o(1-o))   [lane-local: same fragment slots as the forward]
-//   dP -> HBM (token-major, feeds the W_ih/W_hh/bias gradient GEMMs and the dy1 data gradient) and -> LDS;
-//   recurrent dh_{prev} = dP[32 x 512] * W_hh[512 x 128]   (256 MFMA per wave, W_hh^T resident in registers)
-constexpr int BPTT_LDP = 512 + 4;
-constexpr size_t BPTT_LDS_BYTES = sizeof(float) * 2 * 32 * BPTT_LDP;
-
-__global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict__ tape_gates,
-                                                         const float* __restrict__ tape_c,
-                                                         const float* __restrict__ whh_f, const float* __restrict__ whh_b,
-                                                         const float* __restrict__ dh_up, int ldh,
-                                                         float* __restrict__ dg_out, int ldg, int dump_row, SeqGeom g,
-                                                         float* __restrict__ bias_partials /* [ndir][nst][512] */) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* DPs = smem;   // [2][32][BPTT_LDP]
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
-  const int st = blockIdx.x, d = blockIdx.y;
-  const float* whh = d ? whh_b : whh_f;
-
-  // B operand of dh_prev = dP W_hh:  B[k = gate column][j = hidden unit 32w + c] = W_hh[k][32w + c]
-  float wf[256];
-#pragma unroll
-  for (int m = 0; m < 64; ++m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf[4 * m + t] = whh[(int64_t)(8 * m + 4 * hh + t) * LSTM_H + 32 * w + c];
-
-  const int tstride = seq_token_stride(g);
-  // processing order: against the forward order of this direction
-  const int t_first = d ? 0 : g.len - 1, tdir = d ? 1 : -1;
-  unsigned hidx[16], gidx[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int q = st * 32 + ROW32(r, hh);
-    const unsigned tokb = (q < g.nseq ? (unsigned)seq_token_base(g, q) : (unsigned)dump_row) + (unsigned)(t_first * tstride);
-    hidx[r] = tokb * (unsigned)ldh + (unsigned)(d * LSTM_H + 32 * w + c);
-    gidx[r] = tokb * (unsigned)ldg + (unsigned)(d * 512 + 32 * w + c);
-  }
-  const unsigned hstep = (unsigned)(tdir * tstride * ldh), gstep = (unsigned)(tdir * tstride * ldg);
-  // bias gradients (b_ih and b_hh share them) = column sums of dP over valid rows and steps: accumulated here, one
-  // partial row per workgroup, instead of re-reading the 1.4 GB of dP with a column-sum kernel
-  unsigned vmask = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) vmask |= (st * 32 + ROW32(r, hh) < g.nseq ? 1u : 0u) << r;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-
-  f32x16 dh_rec = zero16(), dc_rec = zero16();
-  for (int step = 0; step < g.len; ++step) {
-    const int t = t_first + tdir * step;
-    const int t_prev = t - (d ? -1 : 1);                 // forward-order predecessor of t (d=0: t-1, d=1: t+1)
-    const bool has_prev = t_prev >= 0 && t_prev < g.len;
-    float* dp = DPs + (step & 1) * 32 * BPTT_LDP;
-    const float* tg = tape_gates + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)w * 1024 + lane * 4;
-    const float* tc = tape_c + pre_tile_offset(d, st, t, g.nst, g.len) / 4 + (int64_t)w * 1024 + lane * 4;
-    const float* tcp = tape_c + pre_tile_offset(d, st, has_prev ? t_prev : t, g.nst, g.len) / 4 + (int64_t)w * 1024 + lane * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 i4 = *reinterpret_cast<const float4*>(tg + 0 * 4096 + q * 256);
-      const float4 f4 = *reinterpret_cast<const float4*>(tg + 1 * 4096 + q * 256);
-      const float4 g4 = *reinterpret_cast<const float4*>(tg + 2 * 4096 + q * 256);
-      const float4 o4 = *reinterpret_cast<const float4*>(tg + 3 * 4096 + q * 256);
-      const float4 c4 = *reinterpret_cast<const float4*>(tc + q * 256);
-      float4 p4 = *reinterpret_cast<const float4*>(tcp + q * 256);
-      if (!has_prev) p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float iv[4] = {i4.x, i4.y, i4.z, i4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
-      const float ov[4] = {o4.x, o4.y, o4.z, o4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w}, pv[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * q + e;
-        const float dh = dh_up[hidx[r]] + dh_rec[r];
-        const float tc_ = fast_tanh(cv[e]);
-        const float dc = dc_rec[r] + dh * ov[e] * (1.f - tc_ * tc_);
-        const float dpo = dh * tc_ * ov[e] * (1.f - ov[e]);
-        const float dpi = dc * gv[e] * iv[e] * (1.f - iv[e]);
-        const float dpf = dc * pv[e] * fv[e] * (1.f - fv[e]);
-        const float dpg = dc * iv[e] * (1.f - gv[e] * gv[e]);
-        dc_rec[r] = dc * fv[e];
-        if ((vmask >> r) & 1u) { bsum[0] += dpi; bsum[1] += dpf; bsum[2] += dpg; bsum[3] += dpo; }
-        const int row = ROW32(r, hh);
-        float* lp = dp + row * BPTT_LDP + 32 * w + c;
-        lp[0] = dpi; lp[128] = dpf; lp[256] = dpg; lp[384] = dpo;
-        float* gp = dg_out + gidx[r];
-        gp[0] = dpi; gp[128] = dpf; gp[256] = dpg; gp[384] = dpo;
-        hidx[r] += hstep;
-        gidx[r] += gstep;
-      }
-    }
-    __syncthreads();
-    // dh_rec = dP W_hh  (rows = sequences, K = 512 gate columns, this wave's 32 hidden units)
-    f32x16 acc = zero16();
-    const float* arow = dp + c * BPTT_LDP + 4 * hh;
-#pragma unroll
-    for (int m0 = 0; m0 < 64; m0 += 16) {
-      float4 afr[16];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 8 * (m0 + m));
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        acc = mfma32(afr[m].x, wf[4 * (m0 + m) + 0], acc);
-        acc = mfma32(afr[m].y, wf[4 * (m0 + m) + 1], acc);
-        acc = mfma32(afr[m].z, wf[4 * (m0 + m) + 2], acc);
-        acc = mfma32(afr[m].w, wf[4 * (m0 + m) + 3], acc);
-      }
-    }
-    dh_rec = acc;
-  }
-#pragma unroll
-  for (int gi = 0; gi < 4; ++gi) {
-    const float v = bsum[gi] + __shfl_xor(bsum[gi], 32);
-    if (hh == 0) bias_partials[((size_t)d * g.nst + st) * 512 + gi * LSTM_H + 32 * w + c] = v;
-  }
-}
+// (LSTM backward through time: lstm_bptt.hip)
 
 // ------------------------------------------------------------------------------------------------
 // attention backward (per sequence and head, everything on chip: len <= 256)
@@ -335,8 +220,8 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
 template <int DH>
 struct AttnBwdShape {
   static constexpr int LD = DH + 4;
-  // two row arrays (K,V in phase A; Q,dO in phase B) + three per-query statistics
-  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (2 * LD + 3)); }
+  // two row arrays (K,V in phase A; Q,dO in phase B) + one float4 of per-query statistics
+  static constexpr size_t lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * (2 * LD + 4)); }
 };
 
 // PHASE 0 and PHASE 1 are separate launches (each gets its own register allocation: together they needed 170 VGPRs,
@@ -356,9 +241,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   float* Vs = Ks + ROWS * LD;
   float* Qs = Ks;                      // phase B alias
   float* Ds = Vs;                      // phase B alias (dO)
-  float* Ms = Vs + ROWS * LD;          // row max (log2 domain)
-  float* Ls = Ms + ROWS;               // 1 / row sum
-  float* Es = Ls + ROWS;               // delta
+  float4* St = reinterpret_cast<float4*>(Vs + ROWS * LD);   // per query: row max (log2 domain), 1 / row sum, delta, dropout seed
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
   const int seq = blockIdx.x, head = blockIdx.y;
@@ -441,10 +324,12 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
+    // per-query dropout seed: used here and handed to phase B with the statistics
+    const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head);
     if (hh == 0 && p < len)
-      *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) = make_float4(mx, inv, delta, 0.f);
+      *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) =
+          make_float4(mx, inv, delta, __uint_as_float(qseed));
     // dS^T tile by tile, then dQ = scale * dS K
-    const uint32_t qh = (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head;
     f32x16 dq = zero16();
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb) {
@@ -470,7 +355,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         for (int r = 0; r < 8; ++r) {
           float dpv = dp[r0 + r];
           if (drop.thresh != 0u)
-            dpv = drop_rand(drop.seed, qh, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dpv * drop.inv_keep : 0.f;
+            dpv = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dpv * drop.inv_keep : 0.f;
           const float ds = s[rb][r0 + r] * inv * (dpv - delta);
           dq = mfma32(ds, kk[r], dq);
         }
@@ -504,9 +389,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     for (int p = tid; p < ROWS; p += 64 * NKB) {
       float4 st4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p < len) st4 = *reinterpret_cast<const float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4);
-      Ms[p] = st4.x;
-      Ls[p] = st4.y;
-      Es[p] = st4.z;
+      St[p] = st4;
     }
     for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
       const int p = idx / R4, f = idx % R4;
@@ -543,13 +426,11 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qrow_i = qb * 32 + ROW32(r, hh);
-        const float pm = Ms[qrow_i], pl = Ls[qrow_i], pe = Es[qrow_i];
+        const float4 st4 = St[qrow_i];
+        const float pm = st4.x, pl = st4.y, pe = st4.z;
         const float p2 = key_ok ? fast_exp2(s2[r] * sl2e - pm) * pl : 0.f;
         float keep = 1.f;
-        if (drop.thresh != 0u) {
-          const uint32_t qh = (uint32_t)(tok0 + (int64_t)qrow_i * tstride) * (uint32_t)heads + (uint32_t)head;
-          keep = drop_rand(drop.seed, qh, (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
-        }
+        if (drop.thresh != 0u) keep = drop_rand_q(__float_as_uint(st4.w), (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
         s2[r] = p2 * keep;                          // dropped P (feeds dV)
         dp2[r] = p2 * (dp2[r] * keep - pe);         // dS
         const float qv = Qs[qrow_i * LD + (c < DH ? c : 0)], dv_ = Ds[qrow_i * LD + (c < DH ? c : 0)];

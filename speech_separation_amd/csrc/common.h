@@ -83,17 +83,30 @@ DEV float group_sum(float v) {
 
 // Counter-based dropout randomness for the attention probabilities (train mode, dptn.py:16-21): a pure function of
 // (seed, query token x head, key position), so the forward and both backward phases regenerate identical masks.
-// keep  <=>  drop_rand(...) >= thresh,  thresh = p * 2^32.   (lowbias32 mixer)
+// (lowbias32 mixer)
 DEV uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// Two levels: a full-strength seed per (query token, head) -- computed once per query and hoisted or staged through
+// LDS by the kernels -- and a cheap per-key step on top of it: two multiply-xorshift rounds on 24-bit multiplies
+// (v_mul_u32_u24 / v_mad_u32_u24 issue at full rate, v_mul_lo_u32 at a quarter) returning 24 random bits.
+DEV uint32_t drop_qseed(uint32_t seed, uint32_t qtok_head) { return mix32(seed ^ (qtok_head * 0x9E3779B9u)); }
+DEV uint32_t drop_rand_q(uint32_t qseed, uint32_t key) {
+  uint32_t x = qseed + __umul24(key, 0x9E3779u);
+  x ^= x >> 15;
+  x = __umul24(x, 0xB5297Bu) >> 6;     // bits 6..29 of the 48-bit product's low word: the well-mixed ones
+  x ^= x >> 11;
+  x = __umul24(x, 0x68E31Du) >> 8;
+  return x & 0xffffffu;
+}
+// keep  <=>  drop_rand(...) >= thresh24,  thresh24 = p * 2^24
 DEV uint32_t drop_rand(uint32_t seed, uint32_t qtok_head, uint32_t key) {
-  return mix32(mix32(seed ^ (qtok_head * 0x9E3779B9u)) ^ (key * 0x85EBCA6Bu + 0x165667B1u));
+  return drop_rand_q(drop_qseed(seed, qtok_head), key);
 }
 struct DropCfg {
   uint32_t seed;     // already mixed with the call index (block, path, step)
-  uint32_t thresh;   // 0: no dropout
+  uint32_t thresh;   // p * 2^24 (0: no dropout)
   float inv_keep;    // 1 / (1 - p)
 };
 

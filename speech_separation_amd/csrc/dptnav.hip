@@ -81,7 +81,7 @@ struct dptnav_ctx {
     if (!train || opt_dropout_ppm <= 0) return d;
     const double p = opt_dropout_ppm * 1e-6;
     d.seed = opt_dropout_seed ^ (0x9E3779B9u * (unsigned)(2 * block + path + 1));
-    d.thresh = (unsigned)(p * 4294967296.0);
+    d.thresh = (unsigned)(p * 16777216.0);   // 24 random bits per element (common.h)
     d.inv_keep = (float)(1.0 / (1.0 - p));
     return d;
   }
@@ -731,15 +731,10 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   br.slot = run.slot;
   // 4. LSTM backward through time
   {
-    static bool ready = false;
-    if (!ready) {
-      if (int rc = set_lds(c, lstm_bptt_kernel, BPTT_LDS_BYTES, "lstm bptt")) return rc;
-      ready = true;
-    }
     ProfScope ps(c, CAT_LSTM, st);
-    hipLaunchKernelGGL(lstm_bptt_kernel, dim3(geom.nst, 2), dim3(256), BPTT_LDS_BYTES, st, gates, cst, w.w_hh[0], w.w_hh[1],
-                       DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom, LNP);
-    LAUNCH_CHECK(c, "lstm bptt");
+    const int rc = lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom,
+                                    LNP);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
   }
   // 5. LSTM parameter gradients
   for (int d = 0; d < 2; ++d) {
