@@ -93,11 +93,12 @@ DEV uint32_t mix32(uint32_t x) {
 // (v_mul_u32_u24 / v_mad_u32_u24 issue at full rate, v_mul_lo_u32 at a quarter) returning 24 random bits.
 DEV uint32_t drop_qseed(uint32_t seed, uint32_t qtok_head) { return mix32(seed ^ (qtok_head * 0x9E3779B9u)); }
 DEV uint32_t drop_rand_q(uint32_t qseed, uint32_t key) {
-  uint32_t x = qseed + __umul24(key, 0x9E3779u);
+  // (HIP declares __umul24 as returning int: cast before shifting, or the shifts are arithmetic)
+  uint32_t x = qseed + (uint32_t)__umul24(key, 0x9E3779u);
   x ^= x >> 15;
-  x = __umul24(x, 0xB5297Bu) >> 6;     // bits 6..29 of the 48-bit product's low word: the well-mixed ones
+  x = (uint32_t)__umul24(x, 0xB5297Bu) >> 6;     // bits 6..31 of the product's low word: the well-mixed ones
   x ^= x >> 11;
-  x = __umul24(x, 0x68E31Du) >> 8;
+  x = (uint32_t)__umul24(x, 0x68E31Du) >> 8;
   return x & 0xffffffu;
 }
 // keep  <=>  drop_rand(...) >= thresh24,  thresh24 = p * 2^24

@@ -9,6 +9,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:   # tests/dropout_ref.py
+    sys.path.insert(0, HERE)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -186,6 +186,9 @@ def test_dropout_forward_and_backward_match_autograd_with_the_same_mask(dev, pat
     torch.cuda.synchronize()
     keep = float(mask.mean())
     assert 0.88 < keep < 0.92, keep                       # p = 0.1
+    # integer work: the device mask equals the numpy restatement of the counter-based generator bit for bit
+    from dropout_ref import keep_mask
+    assert np.array_equal(mask.numpy().astype(np.float32), keep_mask(0, path, B, S, K, heads, 100000, 12345))
     eng.set_option("dropout_seed", 54321)
     assert not torch.equal(eng.dropout_mask(0, path, B, S).cpu().double(), mask)   # the seed matters
 

@@ -104,3 +104,24 @@ def test_product_code_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b|oracle[./](dptn_oracle|torch_stock)|import_module\(.oracle",
                                      src, flags=re.M), f"{f} reaches into oracle/"
+
+
+def test_dropout_generator_statistics():
+    """The counter-based keep-mask generator (tests/dropout_ref.py = csrc/common.h drop_rand): keep rate, uniformity
+    and independence between neighbouring keys / queries / heads."""
+    from dropout_ref import drop_qseed, drop_rand_q, keep_mask
+    m = keep_mask(1, 0, 2, 3, 150, 4, 100000, 777).astype(np.float64)       # (6, 4, 150, 150)
+    assert abs(m.mean() - 0.9) < 3e-3
+    c = m - m.mean()
+    var = c.var()
+    tol = 6.0 / np.sqrt(c.size)
+    assert abs((c[..., 1:] * c[..., :-1]).mean() / var) < tol               # adjacent keys
+    assert abs((c[..., 1:, :] * c[..., :-1, :]).mean() / var) < tol         # adjacent queries
+    assert abs((c[:, 1:] * c[:, :-1]).mean() / var) < tol                   # adjacent heads
+    assert not np.array_equal(m, keep_mask(1, 0, 2, 3, 150, 4, 100000, 778))   # the seed matters
+    assert not np.array_equal(m, keep_mask(2, 0, 2, 3, 150, 4, 100000, 777))   # and so does the call site
+    q = np.arange(1 << 14, dtype=np.uint64)
+    u = drop_rand_q(drop_qseed(123, q)[:, None], np.arange(160, dtype=np.uint64)[None, :]) / 2.0 ** 24
+    assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 2e-3
+    h = np.histogram(u, bins=64)[0] / (u.size / 64)
+    assert h.min() > 0.97 and h.max() < 1.03
