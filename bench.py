@@ -188,7 +188,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    env = DistEnv.from_environ(expected_world=args.gpus)
+    # BENCH_REHEARSAL=1: N ranks share cuda:0 and talk over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
+    # (its numbers mean nothing); the real launch is one rank per GPU over RCCL
+    if os.environ.get("BENCH_REHEARSAL") == "1":
+        env = DistEnv.from_environ(expected_world=args.gpus, backend="gloo", device="cuda:0")
+    else:
+        env = DistEnv.from_environ(expected_world=args.gpus)
     dev = env.device
     torch.cuda.set_device(dev)
     cfg, B_default, T, workload = CONFIGS[args.config]

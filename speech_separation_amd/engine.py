@@ -28,6 +28,24 @@ def _check(t: torch.Tensor, name: str, shape: Tuple[int, ...], device: torch.dev
     return t.contiguous()
 
 
+class _DeviceBoundLib:
+    """ctypes library proxy: calls every dptnav_* function inside `torch.cuda.device(device)`."""
+
+    def __init__(self, lib, device):
+        self._lib, self._device, self._cache = lib, device, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw, dev = getattr(self._lib, name), self._device
+
+            def fn(*args, _raw=raw, _dev=dev):
+                with torch.cuda.device(_dev):
+                    return _raw(*args)
+            self._cache[name] = fn
+        return fn
+
+
 class DptnEngine:
     """One handle <-> one device <-> the caller's current stream (include/dptnav.h threading contract)."""
 
@@ -38,7 +56,10 @@ class DptnEngine:
             raise RuntimeError("DptnEngine needs a GPU device (PyTorch-ROCm 'cuda:N'); there is no CPU path")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.lib = _lib.load()
+        # every entry point runs with THIS engine's GPU current (the library creates its internal streams / events on the
+        # current HIP device and launches on the caller's stream, which must belong to it): rank-per-GPU callers need
+        # not have called torch.cuda.set_device themselves
+        self.lib = _DeviceBoundLib(_lib.load(), self.device)
         c = _lib.DptnavConfig(cfg.num_features, cfg.video_emb_size, cfg.hidden_video, cfg.kernel_size_enc,
                               cfg.hidden_dim, cfg.num_blocks, cfg.chunk_size, cfg.step_size, cfg.num_heads,
                               int(cfg.bidir), int(cfg.audio_only), {"dptn": 0, "dprnn": 1}[cfg.arch])

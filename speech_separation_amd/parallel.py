@@ -51,7 +51,7 @@ class DistEnv:
         dev = torch.device(device)
         if world > 1:
             import torch.distributed as dist
-            backend = backend or ("nccl" if dev.type == "cuda" else "gloo")
+            backend = backend or ("nccl" if dev.type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if not dist.is_initialized():
