@@ -273,6 +273,12 @@ def main():
         fits16 = all(-(-int(b_launch * n) // 16) * d <= torch.cuda.get_device_properties(dev).multi_processor_count
                      for n, d in ((S, 2), (K, ndir)))
         lstm_kernel = "lstm16_kernel" if fits16 else "lstm_recurrence_kernel"
+        # a recurrence launch occupies ONE CU per (direction, sequence tile) -- W_hh fills the CU's register file -- so
+        # beside `frac` (against the whole chip's peak, as the contract defines it) the share of the chip it can use
+        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        tile = 16 if fits16 else 32
+        wgs = sum(-(-int(b_launch * n) // tile) * d for n, d in ((S, 2), (K, ndir))) / 2.0    # mean of intra / inter
+        cu_share = min(1.0, wgs / n_cus)
         if iso is not None:
             iso["kernel"] = "lstm_recurrence_kernel"
         value = env.world * B * args.steps / elapsed
@@ -291,6 +297,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_lstm_hbm_traffic.json)",
                          "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (8 * H + 2 * H) * 4,
                          "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
+                         "cus_occupied": round(wgs, 1), "frac_of_occupied_cus": round(achieved / (PEAK_F32_MFMA_TFLOPS * cu_share), 4),
                          "launches_per_step": launches_per_step,
                          "isolated": iso,
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),

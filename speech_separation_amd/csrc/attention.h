@@ -162,3 +162,126 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   }
   ATTN_STAMP(5);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Long sequences (len > 256: more than ~7 s of audio on the inter-chunk path): streaming softmax.
+// ------------------------------------------------------------------------------------------------
+// Same transposed score tiles, but the keys are walked in blocks of 32 with a running (max, sum) per query, and the
+// output is accumulated TRANSPOSED as well:  O^T[d][query] = V^T P^T, with the S^T accumulator registers used as-is
+// as the MFMA *B* operand (k-slot hh <-> key ROW32(r,hh)) and V^T rows as the A operand.  Then every quantity of a
+// query -- its running max, its sum, its 16 output values per lane -- lives in the lanes c = query, so the rescale
+// o *= 2^(m_old - m_new) is lane-local and the only cross-lane traffic per key block is the max / sum exchange
+// between the two lane halves.  One workgroup = one (sequence, head); wave w takes query blocks w, w+4, ...;
+// K / V rows are read straight from global memory (the four waves and the heads' workgroups share them through L2),
+// one key block ahead of the MFMAs.  No LDS, no length limit.  Inference only (no dropout, no backward).
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attention_long_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
+                                                                 SeqGeom g, float scale_log2e) {
+  static_assert(DH == 32 || DH == 16, "head width");
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int seq = blockIdx.x, head = blockIdx.y;
+  const int len = g.len;
+  const int64_t tok0 = seq_token_base(g, seq);
+  const int tstride = seq_token_stride(g);
+  const int ld = 3 * N;
+  const float* base = qkv + head * DH;
+  const int nkb = (len + 31) / 32;
+  const bool dcol = c < DH;                       // DH = 16: only half of the 32 V^T rows exist
+  const int cd = dcol ? c : 0;
+
+  for (int qb = w; qb < nkb; qb += 4) {
+    // Q fragments (B operand of S^T = K Q^T), pre-scaled by log2(e)/sqrt(dh)
+    const int pq = qb * 32 + c;
+    float qf[DH / 2];
+    {
+      const float* row = base + (tok0 + (int64_t)(pq < len ? pq : 0) * tstride) * ld + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        float4 v = *reinterpret_cast<const float4*>(row + 8 * m);
+        if (pq >= len) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        qf[4 * m + 0] = v.x * scale_log2e;
+        qf[4 * m + 1] = v.y * scale_log2e;
+        qf[4 * m + 2] = v.z * scale_log2e;
+        qf[4 * m + 3] = v.w * scale_log2e;
+      }
+    }
+    // key-block operands: K rows (A of S^T: lane = key c, k-slot hh) and V^T (A of O^T: lane = d c, k-slot hh <-> key
+    // ROW32(r,hh)); rows beyond len read row 0 and are masked / zeroed.  Element offsets are 32-bit (host-checked);
+    // two statically named buffers (a runtime-indexed register array would be demoted to scratch).
+    const unsigned koff = (unsigned)(N + 4 * hh), voff = (unsigned)(2 * N + cd);
+    const unsigned tbase = (unsigned)tok0, ts = (unsigned)tstride, ldu = (unsigned)ld;
+    auto fetch = [&](int kb, float4 (&kf)[DH / 8], float (&vf)[16]) {
+      const int key = kb * 32 + c;
+      const float* krow = base + (tbase + (unsigned)(key < len ? key : 0) * ts) * ldu + koff;
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) kf[m] = *reinterpret_cast<const float4*>(krow + 8 * m);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = kb * 32 + ROW32(r, hh);
+        const float v = base[(tbase + (unsigned)(kr < len ? kr : 0) * ts) * ldu + voff];
+        vf[r] = (kr < len && dcol) ? v : 0.f;
+      }
+    };
+    float mrun = -1e30f, lrun = 0.f;
+    f32x16 o = zero16();
+    auto block = [&](int kb, const float4 (&kf)[DH / 8], const float (&vf)[16]) {
+      f32x16 s = zero16();
+#pragma unroll
+      for (int m = 0; m < DH / 8; ++m) {
+        s = mfma32(kf[m].x, qf[4 * m + 0], s);
+        s = mfma32(kf[m].y, qf[4 * m + 1], s);
+        s = mfma32(kf[m].z, qf[4 * m + 2], s);
+        s = mfma32(kf[m].w, qf[4 * m + 3], s);
+      }
+      if ((kb + 1) * 32 > len) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + ROW32(r, hh) >= len) s[r] = -1e30f;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = fast_exp2(mrun - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = fast_exp2(s[r] - mnew);
+        sum += s[r];
+      }
+      sum += __shfl_xor(sum, 32);
+      lrun = lrun * alpha + sum;
+      mrun = mnew;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      // O^T += V^T P^T : A = V^T (lane = d, slot <-> key ROW32(r,hh)), B = the S^T registers (lane = query)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o = mfma32(vf[r], s[r], o);
+    };
+    float4 kfa[DH / 8], kfb[DH / 8];
+    float vfa[16], vfb[16];
+    fetch(0, kfa, vfa);
+    for (int kb = 0; kb < nkb; kb += 2) {
+      if (kb + 1 < nkb) fetch(kb + 1, kfb, vfb);
+      block(kb, kfa, vfa);
+      if (kb + 1 < nkb) {
+        if (kb + 2 < nkb) fetch(kb + 2, kfa, vfa);
+        block(kb + 1, kfb, vfb);
+      }
+    }
+    // o[r] = O^T[d = ROW32(r,hh)][query c]: four 16-byte pieces of the query's output row
+    if (pq < len) {
+      const float inv = fast_rcp(lrun);
+      float* orow = out + (tok0 + (int64_t)pq * tstride) * N + head * DH;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = 8 * j + 4 * hh;
+        if (d0 < DH)
+          *reinterpret_cast<float4*>(orow + d0) =
+              make_float4(o[4 * j + 0] * inv, o[4 * j + 1] * inv, o[4 * j + 2] * inv, o[4 * j + 3] * inv);
+      }
+    }
+  }
+}

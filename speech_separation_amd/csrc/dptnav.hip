@@ -266,8 +266,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
     return c->fail(DPTNAV_ERR_INVALID, "T=%lld gives L=%lld frames < chunk_size=%d", (long long)T, (long long)p->L,
                    g.chunk_size);
   p->S = (p->L - g.chunk_size) / g.step_size + 1;
-  if (g.arch == 0 && (p->S > 256 || g.chunk_size > 256))
-    return c->fail(DPTNAV_ERR_INVALID, "sequence length > 256 unsupported by the attention kernel (S=%lld, K=%d)",
+  if (g.arch == 0 && g.chunk_size > 256)
+    return c->fail(DPTNAV_ERR_INVALID, "chunk_size > 256 unsupported by the attention kernel (S=%lld, K=%d)",
                    (long long)p->S, g.chunk_size);
   {  // token indices are 32-bit inside the kernels: (tokens + dump rows) x widest row must stay below 2^31
     const int64_t widest = std::max<int64_t>(3 * N, 2 * H);
@@ -351,7 +351,15 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
     case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop);
     case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop);
   }
-  return c->fail(DPTNAV_ERR_INVALID, "attention: sequence length %d > 256", g.len);
+  // longer sequences (inter-chunk path of utterances beyond ~7 s): streaming-softmax kernel, inference only
+  if (drop.thresh != 0u) return c->fail(DPTNAV_ERR_INVALID, "attention: dropout needs sequence length <= 256 (got %d)", g.len);
+  {
+    ProfScope ps(c, CAT_ATTN, st);
+    hipLaunchKernelGGL(attention_long_kernel<DH>, dim3(g.nseq, heads), dim3(256), 0, st, qkv, att, N, g,
+                       1.4426950408889634f / sqrtf((float)DH));
+    LAUNCH_CHECK(c, "attention (long)");
+  }
+  return DPTNAV_OK;
 }
 
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
@@ -1128,7 +1136,7 @@ int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, f
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1))
     return h->fail(DPTNAV_ERR_INVALID, "bad block/path %d/%d", block, path);
   if (!x_in || !x_out || x_in == x_out) return h->fail(DPTNAV_ERR_INVALID, "x_in/x_out null or aliased");
-  if (S < 1 || S > 256) return h->fail(DPTNAV_ERR_INVALID, "S=%d out of range", S);
+  if (S < 1 || S > 65535) return h->fail(DPTNAV_ERR_INVALID, "S=%d out of range", S);
   // a T that yields exactly S chunks
   const int64_t L = (int64_t)(S - 1) * h->cfg.step_size + h->cfg.chunk_size;
   const int64_t T = (L - 1) * h->stride + h->cfg.kernel_size_enc;
