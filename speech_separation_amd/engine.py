@@ -201,16 +201,29 @@ class DptnEngine:
 
     # ------------------------------------------------------------------ training step, path level
     def bind_grads(self) -> Dict[str, torch.Tensor]:
-        """Allocate one gradient buffer per parameter slot (library WRITES them) and bind them; returns {key: tensor}."""
+        """Allocate the gradient buffers the library WRITES and bind them; returns {key: tensor}.  All of them are views
+        of ONE flat tensor (`self._grads_flat`, every slot at a 256-byte aligned offset `self._grad_offsets[key]`), so
+        that a step can be handed to autograd with one copy and to RCCL with one collective."""
+        offs, o = {}, 0
+        for key, shape in self.slots:
+            offs[key] = o
+            n = 1
+            for d in shape:
+                n *= int(d)
+            o += (n + 63) // 64 * 64
+        flat = torch.zeros(o, device=self.device)
         grads, ptrs = {}, (C.c_void_p * len(self.slots))()
         for i, (key, shape) in enumerate(self.slots):
-            g = torch.zeros(shape, device=self.device)
+            n = 1
+            for d in shape:
+                n *= int(d)
+            g = flat[offs[key]:offs[key] + n].view(*shape)
             grads[key] = g
             ptrs[i] = g.data_ptr()
         rc = self.lib.dptnav_bind_grads(self._h, ptrs, len(self.slots))
         if rc:
             self._raise(rc, "dptnav_bind_grads")
-        self._grads = grads
+        self._grads, self._grads_flat, self._grad_offsets = grads, flat, offs
         return grads
 
     def train_path_forward(self, block: int, path: int, x: torch.Tensor):

@@ -98,8 +98,16 @@ class _SeparateFn(torch.autograd.Function):
         eng.set_option("dropout_seed", ctx.drop[1])
         eng.train_backward(mix, e1, e2, zeros(d_s1), zeros(d_s2), ctx.tape)
         ctx.tape = None
-        # the library's gradient buffers are reused by the next step: hand autograd its own copies
-        return (None, None, None, None) + tuple(eng._grads[k].clone() for k, _ in eng.slots)
+        # the library's gradient buffers are reused by the next step: hand autograd its own copy -- ONE flat copy whose
+        # per-parameter views autograd adopts as .grad without copying (train.allreduce_gradients finds the flat
+        # tensor again through `_flat_grad`)
+        flat = eng._grads_flat.clone()
+        ctx.module._flat_grad = flat
+        outs = []
+        for k, shape in eng.slots:
+            o = eng._grad_offsets[k]
+            outs.append(flat[o:o + eng._grads[k].numel()].view(*shape))
+        return (None, None, None, None) + tuple(outs)
 
 
 class _DPTNBase(nn.Module):

@@ -44,6 +44,12 @@ def allreduce_gradients(model: nn.Module, env: Optional[DistEnv]) -> None:
         return
     import torch.distributed as dist
     grads = [p.grad for p in model.parameters() if p.grad is not None]
+    # the drop-in hands autograd views of one flat tensor (model._SeparateFn.backward): reduce that tensor in place
+    flat = getattr(model, "_flat_grad", None)
+    if flat is not None and grads and all(g.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for g in grads):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(env.world)
+        return
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(env.world)

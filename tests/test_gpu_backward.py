@@ -136,6 +136,9 @@ def test_training_steps_match_stock_pytorch(dev):
     for _ in range(3):
         batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
         ours.append(train_step(model, batch, SiSNRWavLoss(), opt, max_grad_norm=10.0))
+    # autograd adopted the per-parameter views of the step's ONE flat gradient copy (no 228 copies, one collective)
+    flat = model._flat_grad
+    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in model.parameters())
 
     # the same three steps with stock PyTorch on the CPU
     class Stock(torch.nn.Module):
