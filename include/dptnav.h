@@ -180,6 +180,9 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 hash of (seed, block, path, query token, head, key position): reproducible, identical in forward and
  *                 backward, but NOT PyTorch's Philox stream (parity with the reference is statistical only).  The caller
  *                 changes the seed every step and sets the same seed for the backward of that step.
+ *   "train_overlap" (0/1, default 1): run the training step (dptnav_train_forward / _backward) of a batch >= 2 as two
+ *                 halves on the two internal streams, like the forward ("overlap" = 0 switches this off too).  Must not
+ *                 change between a forward and its backward: the tape layout depends on it.
  *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
  *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:

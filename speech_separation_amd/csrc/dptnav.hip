@@ -47,6 +47,7 @@ struct Run {
   int slot;
   hipEvent_t lstm_wait = nullptr;    // if set: the recurrence launch waits for this event (other half's recurrence)
   hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
+  int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
   unsigned* take_queue(int n) {
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
     slot += n;
@@ -76,11 +77,12 @@ struct dptnav_ctx {
   int opt_lstm_diag = 0;
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
-  DropCfg drop_cfg(int block, int path, bool train) const {
+  DropCfg drop_cfg(int block, int path, bool train, int half = 0) const {
     DropCfg d{0u, 0u, 1.0f};
     if (!train || opt_dropout_ppm <= 0) return d;
     const double p = opt_dropout_ppm * 1e-6;
-    d.seed = opt_dropout_seed ^ (0x9E3779B9u * (unsigned)(2 * block + path + 1));
+    // (a split batch numbers the tokens of each half from 0: the half index keeps their masks apart)
+    d.seed = opt_dropout_seed ^ (0x9E3779B9u * (unsigned)(2 * block + path + 1)) ^ (0x7F4A7C15u * (unsigned)half);
     d.thresh = (unsigned)(p * 16777216.0);   // 24 random bits per element (common.h)
     d.inv_keep = (float)(1.0 / (1.0 - p));
     return d;
@@ -121,6 +123,8 @@ struct dptnav_ctx {
   std::vector<int64_t> numel;
   std::vector<const float*> ptr;
   std::vector<float*> gptr;   // parameter-gradient destinations (dptnav_bind_grads), same slots as ptr
+  std::vector<float*> gptr_half1;   // second half of a split training batch: scratch destinations in the workspace
+  bool opt_train_overlap = true;
   bool bound = false;
   std::string err;
   int stride;
@@ -429,7 +433,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (dptn)
-    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train))) return rc;
+    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train, run.half))) return rc;
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
   if (dptn) {
     ALoadDense al{att, M, N, BM};
@@ -639,6 +643,10 @@ struct BwdRun {
   BwdPlan pl;
   hipStream_t st;
   int slot;
+  float* const* gptr;                // where this run WRITES the parameter gradients (slot order)
+  int half = 0;
+  hipEvent_t lstm_wait = nullptr;    // BPTT launches of the two halves of a split batch are chained like the forward's
+  hipEvent_t lstm_record = nullptr;
   unsigned* take_queue(int n) {
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
     slot += n;
@@ -689,7 +697,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   const dptnav_config& g = c->cfg;
   const PathWeights& w = c->pw[2 * block + path];
   const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
-  auto G = [&](const char* leaf) { return c->gptr[c->slot(pre + leaf)]; };
+  auto G = [&](const char* leaf) { return br.gptr[c->slot(pre + leaf)]; };
   if (w.ndir != 2) return c->fail(DPTNAV_ERR_INVALID, "training step: unidirectional inter-chunk LSTM not supported yet");
   const int K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K;
@@ -738,12 +746,14 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   br.slot = run.slot;
   // 4. LSTM backward through time
+  if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
   {
     ProfScope ps(c, CAT_LSTM, st);
     const int rc = lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom,
                                     LNP);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
   }
+  if (br.lstm_record && hipEventRecord(br.lstm_record, st) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger record");
   // 5. LSTM parameter gradients
   for (int d = 0; d < 2; ++d) {
     const char* sfx = d ? "_reverse" : "";
@@ -810,7 +820,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "attention bwd lds: %s", hipGetErrorString(e));
       ProfScope ps(c, CAT_ATTN, st);
-      const DropCfg drop = c->drop_cfg(block, path, true);
+      const DropCfg drop = c->drop_cfg(block, path, true, br.half);
       hipLaunchKernelGGL(kern0, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
                          geom, scale, drop);
       hipLaunchKernelGGL(kern1, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
@@ -889,7 +899,7 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   const int pad_left = (int)((T - ndec) / 2);
   float *DQ = br.ws + br.pl.dq, *DU = br.ws + br.pl.du, *DZs = br.ws + br.pl.dqkv, *LNP = br.ws + br.pl.lnp,
         *slab = br.ws + br.pl.slab;
-  auto G = [&](const char* name) { return c->gptr[c->slot(name)]; };
+  auto G = [&](const char* name) { return br.gptr[c->slot(name)]; };
   int grid = 0;
   // T2 recompute: q = OLA(Z) W_post^T + b_post + E ; d q, d decoder.weight
   {
@@ -955,7 +965,7 @@ int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* 
   constexpr int FPB = 256 / (N / 4);
   float *DQ = br.ws + br.pl.dq, *DE = br.ws + br.pl.de, *DVI = br.ws + br.pl.dvi, *DV = br.ws + br.pl.dv,
         *slab = br.ws + br.pl.slab, *red = br.ws + br.pl.lnp;
-  auto G = [&](const char* name) { return c->gptr[c->slot(name)]; };
+  auto G = [&](const char* name) { return br.gptr[c->slot(name)]; };
   const bool av = !g.audio_only;
   const unsigned gx = (unsigned)((L + FPB - 1) / FPB);
   hipLaunchKernelGGL(head_bwd_frames_kernel<N>, dim3(gx, B), dim3(256), 0, st, DQ, dX0, av ? vid : nullptr,
@@ -1328,7 +1338,7 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
   make_bwd_plan(h, B, S, &bp);
   if (tape_bytes < tp.total * sizeof(float) || bws_bytes < bp.total * sizeof(float) || ((uintptr_t)bws & 255) != 0)
     return h->fail(DPTNAV_ERR_WORKSPACE, "tape or backward workspace too small / misaligned");
-  BwdRun br{(float*)bws, bp, (hipStream_t)stream, 0};
+  BwdRun br{(float*)bws, bp, (hipStream_t)stream, 0, h->gptr.data()};
   if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), br.st) != hipSuccess)
     return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
   return run_path_backward<128>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp);
@@ -1344,82 +1354,232 @@ static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, Mod
   make_bwd_plan(h, B, (int)pl->S, bp, pl->L, Tv);
   return DPTNAV_OK;
 }
+
+// The training step runs a batch of B >= 2 as TWO halves on the two internal streams, like dptnav_forward (option
+// "train_overlap"): the LSTM forward and BPTT launches fill 57 % of the CUs at B = 16, and the other half's GEMM /
+// attention / weight-gradient kernels take the rest.  Each half has its own tape slice and workspace slice; the second
+// half writes its parameter gradients to scratch buffers in its workspace slice and ONE launch adds them to the bound
+// gradients at the end (fixed order: bit-reproducible).
+struct TrainSplit {
+  int nhalf;
+  int Bh[2];
+  Plan pl[2];
+  ModelTape mt[2];
+  BwdPlan bp[2];
+  size_t tape_off[2], ws_off[2];   // floats
+  size_t scratch_off;              // floats, inside the workspace (half 1's gradient scratch); 0 if nhalf == 1
+  size_t tape_total, ws_total;     // floats
+};
+static size_t grad_scratch_floats(dptnav_handle h) {
+  size_t o = 0;
+  for (size_t i = 0; i < h->names.size(); ++i) o += align64((size_t)dptnav_weight_numel(h, (int)i));
+  return o;
+}
+static int train_split(dptnav_handle h, int B, int64_t T, int Tv, TrainSplit* sp) {
+  sp->nhalf = (h->opt_overlap && h->opt_train_overlap && B >= 2) ? 2 : 1;
+  sp->Bh[0] = sp->nhalf == 2 ? (B + 1) / 2 : B;
+  sp->Bh[1] = sp->nhalf == 2 ? B / 2 : 0;
+  sp->tape_total = sp->ws_total = 0;
+  for (int i = 0; i < sp->nhalf; ++i) {
+    if (int rc = train_shapes(h, sp->Bh[i], T, Tv, &sp->pl[i], &sp->mt[i], &sp->bp[i])) return rc;
+    sp->tape_off[i] = sp->tape_total;
+    sp->tape_total += align64(sp->mt[i].total);
+    sp->ws_off[i] = sp->ws_total;
+    sp->ws_total += align64(std::max(sp->pl[i].total, sp->bp[i].total));
+  }
+  sp->scratch_off = 0;
+  if (sp->nhalf == 2) {
+    sp->scratch_off = sp->ws_total;
+    sp->ws_total += grad_scratch_floats(h);
+  }
+  return DPTNAV_OK;
+}
 size_t dptnav_train_tape_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
   if (!h) return 0;
-  Plan pl; ModelTape mt; BwdPlan bp;
-  if (train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return 0;
-  return mt.total * sizeof(float);
+  TrainSplit sp;
+  if (train_split(h, B, T, Tv, &sp)) return 0;
+  return sp.tape_total * sizeof(float);
 }
 size_t dptnav_train_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
   if (!h) return 0;
-  Plan pl; ModelTape mt; BwdPlan bp;
-  if (train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return 0;
-  return (std::max(pl.total, bp.total)) * sizeof(float);
+  TrainSplit sp;
+  if (train_split(h, B, T, Tv, &sp)) return 0;
+  return sp.ws_total * sizeof(float);
 }
+static int train_fork(dptnav_handle h, const TrainSplit& sp, hipStream_t st, hipStream_t* si) {
+  si[0] = si[1] = st;
+  if (sp.nhalf == 1) return DPTNAV_OK;
+  if (int rc = h->ensure_streams()) return rc;
+  if (hipEventRecord(h->ev_fork, st) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork event");
+  for (int i = 0; i < 2; ++i) {
+    si[i] = h->streams[i];
+    if (hipStreamWaitEvent(si[i], h->ev_fork, 0) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork wait");
+  }
+  return DPTNAV_OK;
+}
+static int train_join(dptnav_handle h, const TrainSplit& sp, hipStream_t st, const hipStream_t* si) {
+  if (sp.nhalf == 1) return DPTNAV_OK;
+  for (int i = 0; i < 2; ++i)
+    if (hipEventRecord(h->ev_join[i], si[i]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess)
+      return h->fail(DPTNAV_ERR_HIP, "join event");
+  return DPTNAV_OK;
+}
+
 int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
                          float* s1, float* s2, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  Plan pl; ModelTape mt; BwdPlan bp;
-  if (int rc = train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return rc;
-  if (int rc = check_common(h, B, T, Tv, ws, ws_bytes, &pl)) return rc;
-  if (!tape || tape_bytes < mt.total * sizeof(float) || ((uintptr_t)tape & 255)) return h->fail(DPTNAV_ERR_WORKSPACE, "tape too small / misaligned");
+  if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "weights not bound: call dptnav_bind_weights first");
+  TrainSplit sp;
+  if (int rc = train_split(h, B, T, Tv, &sp)) return rc;
+  if (!ws || ((uintptr_t)ws & 255) || ws_bytes < sp.ws_total * sizeof(float))
+    return h->fail(DPTNAV_ERR_WORKSPACE, "workspace too small / misaligned: %zu < %zu bytes", ws_bytes, sp.ws_total * sizeof(float));
+  if (!tape || tape_bytes < sp.tape_total * sizeof(float) || ((uintptr_t)tape & 255)) return h->fail(DPTNAV_ERR_WORKSPACE, "tape too small / misaligned");
   if (!mix || !s1 || !s2 || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1))) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
-  Run run;
-  if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
-  float* tb = (float*)tape;
-  if (int rc = run_head<128>(h, run, mix, e1, e2, B, T, Tv, tb + mt.E, tb + mt.X0, tb + mt.vid)) return rc;
+  hipStream_t st = (hipStream_t)stream, si[2];
+  if (int rc = train_fork(h, sp, st, si)) return rc;
   const int nb = h->cfg.num_blocks;
-  for (int p = 0; p < 2 * nb; ++p) {
-    float* pt = tb + mt.paths + (size_t)p * mt.path_stride;
-    PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run.ws + pl.pre, pt + mt.pt.hc, pt + mt.pt.gates,
-                pt + mt.pt.cst, true};
-    if (int rc = run_path<128>(h, run, p / 2, p % 2, tb + mt.X0 + (size_t)p * mt.x_stride,
-                               tb + mt.X0 + (size_t)(p + 1) * mt.x_stride, B, (int)pl.S, &pb))
+  const int64_t Cv = h->cfg.audio_only ? 0 : h->cfg.video_emb_size;
+  Run run[2];
+  float* tb[2];
+  int64_t b0[2] = {0, sp.Bh[0]};
+  for (int i = 0; i < sp.nhalf; ++i) {
+    if (int rc = begin_run(h, &run[i], (float*)ws + sp.ws_off[i], sp.pl[i], si[i])) return rc;
+    run[i].half = i;
+    tb[i] = (float*)tape + sp.tape_off[i];
+    const ModelTape& mt = sp.mt[i];
+    if (int rc = run_head<128>(h, run[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr, e2 ? e2 + b0[i] * Cv * Tv : nullptr,
+                               sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid))
       return rc;
   }
+  // the halves advance in lock step on the host; their recurrences are chained by events as in dptnav_forward
+  bool have_prev = false;
+  for (int p = 0; p < 2 * nb; ++p)
+    for (int i = 0; i < sp.nhalf; ++i) {
+      const ModelTape& mt = sp.mt[i];
+      if (sp.nhalf == 2) {
+        run[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
+        run[i].lstm_record = h->ev_lstm[i];
+      }
+      float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
+      PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run[i].ws + sp.pl[i].pre, pt + mt.pt.hc, pt + mt.pt.gates,
+                  pt + mt.pt.cst, true};
+      if (int rc = run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
+                                 tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb))
+        return rc;
+      have_prev = true;
+    }
   // tail: Z (separation-conv output) is needed again by the backward -> kept on the tape
-  return run_tail<128>(h, run, tb + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb + mt.E, B, T, s1, s2, tb + mt.Z);
+  for (int i = 0; i < sp.nhalf; ++i) {
+    const ModelTape& mt = sp.mt[i];
+    if (int rc = run_tail<128>(h, run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, sp.Bh[i], T,
+                               s1 + b0[i] * T, s2 + b0[i] * T, tb[i] + mt.Z))
+      return rc;
+  }
+  return train_join(h, sp, st, si);
 }
+
+// grads[i] += scratch[i] for up to GRAD_ADD_MAX parameters per launch (pointers travel as kernel arguments)
+constexpr int GRAD_ADD_MAX = 96;
+struct GradAddArgs {
+  float* dst[GRAD_ADD_MAX];
+  const float* src[GRAD_ADD_MAX];
+  int n[GRAD_ADD_MAX];
+};
+__global__ void grad_add_kernel(GradAddArgs a) {
+  const int e = blockIdx.x;
+  float* d = a.dst[e];
+  const float* s = a.src[e];
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < a.n[e]; i += gridDim.y * blockDim.x) d[i] += s[i];
+}
+
 int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, const float* e2, const float* d_s1,
                           const float* d_s2, int B, int64_t T, int Tv, void* tape, size_t tape_bytes, void* ws,
                           size_t ws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  Plan pl; ModelTape mt; BwdPlan bp;
-  if (int rc = train_shapes(h, B, T, Tv, &pl, &mt, &bp)) return rc;
+  TrainSplit sp;
+  if (int rc = train_split(h, B, T, Tv, &sp)) return rc;
   if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "weights not bound");
   if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
-  if (!tape || tape_bytes < mt.total * sizeof(float) || !ws || ws_bytes < bp.total * sizeof(float) || ((uintptr_t)ws & 255))
+  if (!tape || tape_bytes < sp.tape_total * sizeof(float) || !ws || ws_bytes < sp.ws_total * sizeof(float) || ((uintptr_t)ws & 255))
     return h->fail(DPTNAV_ERR_WORKSPACE, "tape or workspace too small / misaligned");
   if (!mix || !d_s1 || !d_s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
-  hipStream_t st = (hipStream_t)stream;
-  BwdRun br{(float*)ws, bp, st, 0};
-  if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st) != hipSuccess)
-    return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
-  Run run;
-  run.ws = br.ws;
-  run.pl = Plan{};
-  run.pl.queue = bp.queue;
-  run.st = st;
-  run.slot = 0;
-  float* tb = (float*)tape;
-  const int nb = h->cfg.num_blocks, S = (int)pl.S;
-  float* dcur = br.ws + bp.dxa;
-  float* dnext = br.ws + bp.dxb;
-  if (int rc = run_tail_backward<128>(h, br, run, tb + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb + mt.E, tb + mt.Z, d_s1, d_s2,
-                                      dcur, B, T, pl.L, S))
-    return rc;
-  for (int p = 2 * nb - 1; p >= 0; --p) {
-    if (br.slot > QUEUE_SLOTS - 64) {   // plenty of launches per path: recycle the ticket counters
-      if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st) != hipSuccess)
-        return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
-      br.slot = 0;
+  hipStream_t st = (hipStream_t)stream, si[2];
+  if (int rc = train_fork(h, sp, st, si)) return rc;
+  const int nb = h->cfg.num_blocks;
+  const int64_t Cv = h->cfg.audio_only ? 0 : h->cfg.video_emb_size;
+  const int64_t b0[2] = {0, sp.Bh[0]};
+  if (sp.nhalf == 2) {   // half 1 writes its parameter gradients to scratch
+    h->gptr_half1.resize(h->names.size());
+    size_t o = sp.scratch_off;
+    for (size_t i = 0; i < h->names.size(); ++i) {
+      h->gptr_half1[i] = (float*)ws + o;
+      o += align64((size_t)dptnav_weight_numel(h, (int)i));
     }
-    float* pt = tb + mt.paths + (size_t)p * mt.path_stride;
-    if (int rc = run_path_backward<128>(h, br, p / 2, p % 2, tb + mt.X0 + (size_t)p * mt.x_stride, dcur, dnext, B, S, pt, mt.pt))
-      return rc;
-    std::swap(dcur, dnext);
   }
-  return run_head_backward<128>(h, br, mix, e1, e2, tb + mt.vid, dcur, B, T, pl.L, S, Tv);
+  BwdRun br[2];
+  Run run[2];
+  float *tb[2], *dcur[2], *dnext[2];
+  for (int i = 0; i < sp.nhalf; ++i) {
+    const BwdPlan& bp = sp.bp[i];
+    br[i] = BwdRun{(float*)ws + sp.ws_off[i], bp, si[i], 0, i == 0 ? h->gptr.data() : h->gptr_half1.data()};
+    br[i].half = i;
+    if (hipMemsetAsync(br[i].ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), si[i]) != hipSuccess)
+      return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+    run[i].ws = br[i].ws;
+    run[i].pl = Plan{};
+    run[i].pl.queue = bp.queue;
+    run[i].st = si[i];
+    run[i].slot = 0;
+    run[i].half = i;
+    tb[i] = (float*)tape + sp.tape_off[i];
+    dcur[i] = br[i].ws + bp.dxa;
+    dnext[i] = br[i].ws + bp.dxb;
+    const ModelTape& mt = sp.mt[i];
+    if (int rc = run_tail_backward<128>(h, br[i], run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, tb[i] + mt.Z,
+                                        d_s1 + b0[i] * T, d_s2 + b0[i] * T, dcur[i], sp.Bh[i], T, sp.pl[i].L, (int)sp.pl[i].S))
+      return rc;
+  }
+  bool have_prev = false;
+  for (int p = 2 * nb - 1; p >= 0; --p)
+    for (int i = 0; i < sp.nhalf; ++i) {
+      const ModelTape& mt = sp.mt[i];
+      if (br[i].slot > QUEUE_SLOTS - 64) {   // plenty of launches per path: recycle the ticket counters
+        if (hipMemsetAsync(br[i].ws + sp.bp[i].queue, 0, QUEUE_SLOTS * sizeof(unsigned), si[i]) != hipSuccess)
+          return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+        br[i].slot = 0;
+      }
+      if (sp.nhalf == 2) {
+        br[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
+        br[i].lstm_record = h->ev_lstm[i];
+      }
+      float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
+      if (int rc = run_path_backward<128>(h, br[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride, dcur[i], dnext[i],
+                                          sp.Bh[i], (int)sp.pl[i].S, pt, mt.pt))
+        return rc;
+      std::swap(dcur[i], dnext[i]);
+      have_prev = true;
+    }
+  for (int i = 0; i < sp.nhalf; ++i)
+    if (int rc = run_head_backward<128>(h, br[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr,
+                                        e2 ? e2 + b0[i] * Cv * Tv : nullptr, tb[i] + sp.mt[i].vid, dcur[i], sp.Bh[i], T,
+                                        sp.pl[i].L, (int)sp.pl[i].S, Tv))
+      return rc;
+  if (int rc = train_join(h, sp, st, si)) return rc;
+  if (sp.nhalf == 2) {
+    const int n = (int)h->names.size();
+    for (int lo = 0; lo < n; lo += GRAD_ADD_MAX) {
+      GradAddArgs a{};
+      const int cnt = std::min(GRAD_ADD_MAX, n - lo);
+      for (int e = 0; e < cnt; ++e) {
+        a.dst[e] = h->gptr[lo + e];
+        a.src[e] = h->gptr_half1[lo + e];
+        a.n[e] = (int)dptnav_weight_numel(h, lo + e);
+      }
+      hipLaunchKernelGGL(grad_add_kernel, dim3(cnt, 8), dim3(256), 0, st, a);
+      LAUNCH_CHECK(h, "gradient add");
+    }
+  }
+  return DPTNAV_OK;
 }
 
 // test helper: the keep-mask (1/0) the attention kernels of (block, path) use under the current dropout options
@@ -1441,6 +1601,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
+  else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
