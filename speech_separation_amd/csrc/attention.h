@@ -10,9 +10,9 @@
 //   * K, V of the (sequence, head) are staged once in LDS (rows >= len are zero).
 //   * scores are computed TRANSPOSED: S^T[key][query] = K Q^T, so lane (c,hh) holds 16*NKB scores that
 //     all belong to query c -> the row max / row sum are register-local plus ONE cross-half shuffle.
-//   * P V: the accumulator register (rb, r) of S^T is used AS-IS as the MFMA A operand (k-slot hh means
-//     key rb*32 + ROW32(r,hh)); the B operand is the matching V row, read from LDS.  No transposes,
-//     no LDS round trip for P.
+//   * P V is accumulated transposed, O^T = V^T P^T: the accumulator register (rb, r) of S^T is used AS-IS as the
+//     MFMA B operand (k-slot hh means key rb*32 + ROW32(r,hh)); the A operand is the matching V row, read from
+//     LDS.  No transposes, no LDS round trip for P, and every output value of a query stays in the query's lane.
 //   * token addressing is strided (SeqGeom), so intra and inter views read the same QKV buffer.
 #pragma once
 #include "common.h"
@@ -139,7 +139,11 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         s[rb][r] = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
   }
 
-  // ---- O = P V: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them ----
+  ATTN_STAMP(3);
+  // ---- O^T = V^T P^T: V rows are fetched one key block (16 ds_read_b32) ahead of the MFMAs that use them.  The
+  //      output is accumulated TRANSPOSED (A = V^T: lane = d, k-slot hh <-> key ROW32(r,hh); B = the S^T registers:
+  //      lane = query), so a lane ends up with 16 output values of ITS query: the normaliser is lane-local and the
+  //      row leaves as 16-byte pieces (no cross-lane traffic in the epilogue) ----
   f32x16 o = zero16();
   const float* vcol = Vs + (4 * hh) * Sh::LDV + c;
 #pragma unroll
@@ -148,17 +152,23 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
 #pragma unroll
     for (int r = 0; r < 16; ++r) vv[r] = vcol[(rb * 32 + (r & 3) + 8 * (r >> 2)) * Sh::LDV];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o = mfma32(s[rb][r], vv[r], o);
+    for (int r = 0; r < 16; ++r) o = mfma32(vv[r], s[rb][r], o);
   }
 
   ATTN_STAMP(4);
-  // ---- normalise and store: reg r of lane (c,hh) is O[query ROW32(r,hh)][d = c] -----------------
+  // ---- normalise and store: reg 4j+i of lane (c,hh) is O[query c][d = 8j + 4hh + i] ---------------------------
+  {
+    const int p = qb * 32 + c;
+    if (p < len) {
+      float* orow = out + (tok0 + (int64_t)p * tstride) * N + head * DH;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ql = ROW32(r, hh);
-    const float iv = __shfl(inv, ql);  // lane ql holds the normaliser of query ql
-    const int p = qb * 32 + ql;
-    if (p < len && c < DH) out[(tok0 + (int64_t)p * tstride) * N + head * DH + c] = o[r] * iv;
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = 8 * j + 4 * hh;
+        if (d0 < DH)
+          *reinterpret_cast<float4*>(orow + d0) =
+              make_float4(o[4 * j + 0] * inv, o[4 * j + 1] * inv, o[4 * j + 2] * inv, o[4 * j + 3] * inv);
+      }
+    }
   }
   ATTN_STAMP(5);
 }
