@@ -46,9 +46,9 @@ struct ALoadCols {
   int lda, col0, bm;
   bool relu;
   DEV float4 load4(int tile, int row, int k4) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v = *reinterpret_cast<const float4*>(A + r * lda + col0 + 4 * k4);
+    const int64_t r0 = (int64_t)tile * bm;
+    if (r0 + row >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)(row * lda + col0 + 4 * k4));
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
   }

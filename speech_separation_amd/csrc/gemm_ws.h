@@ -17,9 +17,29 @@
 //                          through LDS, a row of the tile is handled by GROUP = WGCOLS/4 adjacent lanes
 //                          (so LayerNorm statistics are a sub-wave shuffle reduction).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "lstm.h"
 #include "lstm16.h"
+
+// phase stamps for tools/microbench/gemm_phases.hip (a diagnostic build defines these; the product build does not)
+#ifndef GEMM_STAMP
+#define GEMM_STAMP_DECL
+#define GEMM_STAMP(i)
+#define GEMM_STAMP_ACC(i, x)
+#endif
+
+// Epilogues may declare per-column constants (bias, LayerNorm gamma / beta ...) that the engine loads ONCE per
+// workgroup, before the tile loop:   struct Cols {...};  Cols cols(colgroup, c4) const;   row(..., const Cols&).
+// (Loaded inside row() they cost two dependent L1 round trips per pass and tile -- stamps: 3.5 k of the 13.3 k cycles a
+// wave spent per tile of the out-projection GEMM.)
+template <class E, class = void>
+struct epi_has_cols : std::false_type {};
+template <class E>
+struct epi_has_cols<E, std::void_t<typename E::Cols>> : std::true_type {};
+struct EpiNoCols {};
+struct EpiColsFallback { using Cols = EpiNoCols; };
 
 template <int KIN, int NT, int WR, int WC>
 struct GemmShape {
@@ -93,6 +113,17 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   // (dptnav_forward overlaps two half-batches), workgroups that start late simply find fewer tickets left.
   // (thread 0 always holds the ticket AFTER the next one in a register, so the atomic's round trip -- a microsecond
   // when exposed in front of a barrier -- overlaps a whole tile of MFMAs)
+  // per-column epilogue constants of this thread's NPASS row-space slots (identical across tiles)
+  using EpiCols = typename std::conditional<epi_has_cols<Epi>::value, Epi, EpiColsFallback>::type::Cols;
+  // (hoisted out of the tile loop unless the kernel is already at its register limit: with KIN = 256 the twelve extra
+  //  registers turned into AGPR shuffles inside the loop, +3.6 %, with or without smaller fragment batches)
+  constexpr bool HOIST_COLS = epi_has_cols<Epi>::value && !Epi::DIRECT && KIN < 256;
+  EpiCols ecols[NPASS];
+  if constexpr (HOIST_COLS) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) ecols[p] = epi.cols(colgroup, (p * 256 + tid) % C4);
+  }
+
   unsigned* queue = tile_queue + colgroup;
   int ticket_ahead = 0;
   if (tid == 0) {
@@ -101,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float4 pf[NLD];
-  int tile = s_next[0];
+  int tile = __builtin_amdgcn_readfirstlane(s_next[0]);
   if (tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -110,7 +141,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     }
   }
   int buf = 0;
+  GEMM_STAMP_DECL
   while (tile < ntiles) {
+    GEMM_STAMP(0);
     float* Ab = As + buf * (Sh::BM * Sh::LDA);
     if (tid == 0) {                                            // publish the next ticket, request the one after it
       s_next[buf ^ 1] = ticket_ahead;
@@ -122,8 +155,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
     }
     __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
+    GEMM_STAMP(1);
 
-    const int next = s_next[buf ^ 1];
+    const int next = __builtin_amdgcn_readfirstlane(s_next[buf ^ 1]);   // wave-uniform: scalar address arithmetic
     if (next < ntiles) {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
@@ -141,6 +175,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       }
     }
 
+    GEMM_STAMP(2);
     // ---- A fragments + MFMA --------------------------------------------------------------------
     f32x16 acc[NT];
 #pragma unroll
@@ -166,6 +201,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       }
     }
 
+    GEMM_STAMP_ACC(3, acc[NT - 1][15]);
     if constexpr (Epi::DIRECT) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
@@ -178,14 +214,18 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) Cs[(wr * 32 + ROW32(r, hh)) * Sh::LDC + col] = acc[nt][r];
       }
       __syncthreads();
+      GEMM_STAMP(4);
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const int idx = p * 256 + tid;
         const int row = idx / C4, c4 = idx % C4;
         const float4 v = *reinterpret_cast<const float4*>(&Cs[row * Sh::LDC + 4 * c4]);
-        epi.row(tile, row, colgroup, c4, v, epf[p]);
+        if constexpr (HOIST_COLS) epi.row(tile, row, colgroup, c4, v, epf[p], ecols[p]);
+        else if constexpr (epi_has_cols<Epi>::value) epi.row(tile, row, colgroup, c4, v, epf[p], epi.cols(colgroup, c4));
+        else epi.row(tile, row, colgroup, c4, v, epf[p]);
       }
     }
+    GEMM_STAMP(5);
     tile = next;
     buf ^= 1;
   }
@@ -202,9 +242,10 @@ struct ALoadDense {
   int lda;
   int bm;
   DEV float4 load4(int tile, int row, int k4) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4*>(A + r * lda + 4 * k4);
+    // (wave-uniform tile base + an offset that does not change from tile to tile: no 64-bit multiply per load)
+    const int64_t r0 = (int64_t)tile * bm;
+    if (r0 + row >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)(row * lda + 4 * k4));
   }
 };
 
@@ -255,14 +296,14 @@ struct EpiBiasStore {
   int ldo;
   int bm;
   int wgcols;
+  struct Cols { float4 b; };
+  DEV Cols cols(int colgroup, int c4) const { return Cols{*reinterpret_cast<const float4*>(bias + colgroup * wgcols + 4 * c4)}; }
   DEV float4 prefetch(int, int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
-  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 /*pre*/) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    if (r >= M) return;
-    const int col = colgroup * wgcols + 4 * c4;
-    const float4 b = *reinterpret_cast<const float4*>(bias + col);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    *reinterpret_cast<float4*>(out + r * ldo + col) = v;
+  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 /*pre*/, const Cols& k) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    if (r0 + row >= M) return;
+    v.x += k.b.x; v.y += k.b.y; v.z += k.b.z; v.w += k.b.w;
+    *reinterpret_cast<float4*>(out + r0 * ldo + (unsigned)(row * ldo + colgroup * wgcols + 4 * c4)) = v;
   }
 };
 
@@ -279,29 +320,32 @@ struct EpiBiasResLN {
   int64_t M;
   int ld;
   int bm;
-  DEV float4 prefetch(int tile, int row, int c4) const {   // the residual row: independent of the product
-    const int64_t r = (int64_t)tile * bm + row;
-    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  struct Cols { float4 b, ga, be; };
+  DEV Cols cols(int /*colgroup*/, int c4) const {
+    return Cols{*reinterpret_cast<const float4*>(bias + 4 * c4), *reinterpret_cast<const float4*>(gamma + 4 * c4),
+                *reinterpret_cast<const float4*>(beta + 4 * c4)};
   }
-  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    const bool ok = r < M;
-    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+  DEV float4 prefetch(int tile, int row, int c4) const {   // the residual row: independent of the product
+    const int64_t r0 = (int64_t)tile * bm;
+    return r0 + row < M ? *reinterpret_cast<const float4*>(res + r0 * ld + (unsigned)(row * ld + 4 * c4))
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x, const Cols& k) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const bool ok = r0 + row < M;
+    v.x += k.b.x + x.x; v.y += k.b.y + x.y; v.z += k.b.z + x.z; v.w += k.b.w + x.w;
     const float s = group_sum<GROUP>((v.x + v.y) + (v.z + v.w));
     const float mu = s * (1.0f / (4 * GROUP));
     const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
     const float q = group_sum<GROUP>((dx * dx + dy * dy) + (dz * dz + dw * dw));
     const float rstd = rsqrtf(q * (1.0f / (4 * GROUP)) + 1e-5f);
     if (!ok) return;
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
-    const float4 be = *reinterpret_cast<const float4*>(beta + 4 * c4);
     float4 y;
-    y.x = dx * rstd * ga.x + be.x;
-    y.y = dy * rstd * ga.y + be.y;
-    y.z = dz * rstd * ga.z + be.z;
-    y.w = dw * rstd * ga.w + be.w;
-    *reinterpret_cast<float4*>(out + r * ld + 4 * c4) = y;
+    y.x = dx * rstd * k.ga.x + k.be.x;
+    y.y = dy * rstd * k.ga.y + k.be.y;
+    y.z = dz * rstd * k.ga.z + k.be.z;
+    y.w = dw * rstd * k.ga.w + k.be.w;
+    *reinterpret_cast<float4*>(out + r0 * ld + (unsigned)(row * ld + 4 * c4)) = y;
   }
 };
 
