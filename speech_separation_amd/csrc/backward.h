@@ -52,6 +52,15 @@ struct ALoadCols {
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
   }
+  // GEMM-engine form (rows beyond M are never stored there): clamped, branch-free.  The weight-gradient kernels need
+  // the zero-filling load4 above (padded rows must not contribute to the sums).
+  DEV float4 load4c(int tile, int row, int k4) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);
+    float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((row < last ? row : last) * lda + col0 + 4 * k4));
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+  }
 };
 
 template <int NN, int KK>

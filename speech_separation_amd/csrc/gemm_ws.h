@@ -18,6 +18,7 @@
 //                          (so LayerNorm statistics are a sub-wave shuffle reduction).
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "lstm.h"
@@ -28,6 +29,7 @@
 #define GEMM_STAMP_DECL
 #define GEMM_STAMP(i)
 #define GEMM_STAMP_ACC(i, x)
+#define GEMM_STAMP_END
 #endif
 
 // Epilogues may declare per-column constants (bias, LayerNorm gamma / beta ...) that the engine loads ONCE per
@@ -39,6 +41,26 @@ struct epi_has_cols : std::false_type {};
 template <class E>
 struct epi_has_cols<E, std::void_t<typename E::Cols>> : std::true_type {};
 struct EpiNoCols {};
+// Epilogues may opt in (static constexpr bool PIN_SCHEDULE = true) to the hand-pinned schedule of the N -> N kernels
+// (fragment batch in front of the MFMAs, two accumulation chains, prefetched operands held behind the MFMA block):
+// measured on the out-projection + LayerNorm kernel; other shapes were faster with the compiler's own schedule.
+template <class E, class = void>
+struct epi_pins : std::false_type {};
+template <class E>
+struct epi_pins<E, std::enable_if_t<E::PIN_SCHEDULE>> : std::true_type {};
+// Loaders / epilogues may offer BRANCH-FREE variants `load4c` / `prefetchc` that clamp an out-of-range row to the last
+// valid one instead of returning zeros (the engine never stores such rows, so their content is irrelevant to it).
+// Straight-line code lets the compiler count outstanding memory operations exactly: with the bounds branches it fell
+// back to s_waitcnt vmcnt(0) in front of the MFMA block (exposing the prefetch it had just issued) and at the loop top
+// (waiting for the previous tile's stores to retire).
+template <class T, class = void>
+struct has_load4c : std::false_type {};
+template <class T>
+struct has_load4c<T, std::void_t<decltype(std::declval<const T&>().load4c(0, 0, 0))>> : std::true_type {};
+template <class T, class = void>
+struct has_prefetchc : std::false_type {};
+template <class T>
+struct has_prefetchc<T, std::void_t<decltype(std::declval<const T&>().prefetchc(0, 0, 0))>> : std::true_type {};
 struct EpiColsFallback { using Cols = EpiNoCols; };
 
 template <int KIN, int NT, int WR, int WC>
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   using EpiCols = typename std::conditional<epi_has_cols<Epi>::value, Epi, EpiColsFallback>::type::Cols;
   // (hoisted out of the tile loop unless the kernel is already at its register limit: with KIN = 256 the twelve extra
   //  registers turned into AGPR shuffles inside the loop, +3.6 %, with or without smaller fragment batches)
+  constexpr bool PIN = epi_pins<Epi>::value && NT == 1 && KIN < 256;
   constexpr bool HOIST_COLS = epi_has_cols<Epi>::value && !Epi::DIRECT && KIN < 256;
   EpiCols ecols[NPASS];
   if constexpr (HOIST_COLS) {
@@ -133,13 +156,15 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   __syncthreads();
   float4 pf[NLD];
   int tile = __builtin_amdgcn_readfirstlane(s_next[0]);
-  if (tile < ntiles) {
+  auto load_tile = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
-      pf[i] = aload.load4(tile, idx / K4, idx % K4);
+      if constexpr (has_load4c<ALoad>::value) pf[i] = aload.load4c(t, idx / K4, idx % K4);
+      else pf[i] = aload.load4(t, idx / K4, idx % K4);
     }
-  }
+  };
+  if (tile < ntiles) load_tile(tile);
   int buf = 0;
   GEMM_STAMP_DECL
   while (tile < ntiles) {
@@ -158,20 +183,15 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     GEMM_STAMP(1);
 
     const int next = __builtin_amdgcn_readfirstlane(s_next[buf ^ 1]);   // wave-uniform: scalar address arithmetic
-    if (next < ntiles) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int idx = i * 256 + tid;
-        pf[i] = aload.load4(next, idx / K4, idx % K4);
-      }
-    }
+    if (next < ntiles) load_tile(next);
     // epilogue operands that do not depend on the product (residual rows ...) are requested now as well
     float4 epf[NPASS];
     if constexpr (!Epi::DIRECT) {
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const int idx = p * 256 + tid;
-        epf[p] = epi.prefetch(tile, idx / C4, idx % C4);
+        if constexpr (has_prefetchc<Epi>::value) epf[p] = epi.prefetchc(tile, idx / C4, idx % C4);
+        else epf[p] = epi.prefetch(tile, idx / C4, idx % C4);
       }
     }
 
@@ -180,6 +200,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    f32x16 acc_odd = zero16();   // (PIN only)
     {
       // fragments are fetched in batches of 16 x ds_read_b128 BEFORE the MFMAs that use them: a read placed
       // between MFMAs is followed by s_waitcnt lgkmcnt(0) and exposes a full LDS round trip per k-chunk
@@ -190,17 +211,46 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         float4 afr[BATCH];
 #pragma unroll
         for (int m = 0; m < BATCH; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 8 * (m0 + m));
+        // (without the wait AND the scheduling barrier the compiler pairs every read with its MFMAs and waits for it
+        //  there -- 16 exposed LDS round trips per tile; MFMAs are no memory operations, a "memory" clobber alone does
+        //  not keep them behind the reads)
+        // (only for NT == 1: with several column blocks per wave the compiler's pairing hides the LDS latency behind
+        //  the other blocks' MFMAs and was measured faster than the up-front wait)
+        if constexpr (PIN) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int m = 0; m < BATCH; ++m) {
           const float av[4] = {afr[m].x, afr[m].y, afr[m].z, afr[m].w};
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt)
+          for (int tt = 0; tt < 4; ++tt) {
+            if constexpr (PIN) {
+              // a single accumulator makes every MFMA wait for the previous one (64-cycle issue, ~80-cycle dependent
+              // latency: +1 k cycles per 64 MFMAs): two interleaved chains, summed once at the end
+              if (tt & 1) acc_odd = mfma32(av[tt], wf[0][4 * (m0 + m) + tt], acc_odd);
+              else acc[0] = mfma32(av[tt], wf[0][4 * (m0 + m) + tt], acc[0]);
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[tt], wf[nt][4 * (m0 + m) + tt], acc[nt]);
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(av[tt], wf[nt][4 * (m0 + m) + tt], acc[nt]);
+            }
+          }
         }
+      }
+      if constexpr (PIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += acc_odd[r];
       }
     }
 
+    // Keep epilogue arithmetic on the prefetched operands (bias + residual ...) behind the MFMA block: scheduled in
+    // front of it, it waited (s_waitcnt vmcnt(0)) for loads issued a moment earlier.  The empty asm makes the operands
+    // "produced" here; plain arithmetic is not ordered by sched_barrier at instruction selection.
+    if constexpr (PIN && !Epi::DIRECT) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) asm volatile("" : "+v"(epf[p].x), "+v"(epf[p].y), "+v"(epf[p].z), "+v"(epf[p].w));
+    }
     GEMM_STAMP_ACC(3, acc[NT - 1][15]);
     if constexpr (Epi::DIRECT) {
 #pragma unroll
@@ -229,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     tile = next;
     buf ^= 1;
   }
+  GEMM_STAMP_END
   if constexpr (Epi::HAS_FINISH) epi.finish(smem, tid);   // e.g. per-workgroup partial sums of parameter gradients
 }
 
@@ -246,6 +297,11 @@ struct ALoadDense {
     const int64_t r0 = (int64_t)tile * bm;
     if (r0 + row >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
     return *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)(row * lda + 4 * k4));
+  }
+  DEV float4 load4c(int tile, int row, int k4) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);   // wave-uniform
+    return *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((row < last ? row : last) * lda + 4 * k4));
   }
 };
 
@@ -281,6 +337,12 @@ struct ALoadSeqTile {
     const int64_t tok = seq_token_base(g, q) + (int64_t)t * seq_token_stride(g);
     return *reinterpret_cast<const float4*>(A + tok * lda + 4 * k4);
   }
+  DEV float4 load4c(int tile, int row, int k4) const {   // padded sequences read the last real one
+    const int st = tile / g.len, t = tile - st * g.len;
+    const int q = st * 32 + row;
+    const int64_t tok = seq_token_base(g, q < g.nseq ? q : g.nseq - 1) + (int64_t)t * seq_token_stride(g);
+    return *reinterpret_cast<const float4*>(A + tok * lda + 4 * k4);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -312,6 +374,7 @@ template <int GROUP>
 struct EpiBiasResLN {
   static constexpr bool DIRECT = false;
   static constexpr bool HAS_FINISH = false;
+  static constexpr bool PIN_SCHEDULE = true;
   float* out;
   const float* bias;
   const float* res;    // [M][ld]
@@ -329,6 +392,11 @@ struct EpiBiasResLN {
     const int64_t r0 = (int64_t)tile * bm;
     return r0 + row < M ? *reinterpret_cast<const float4*>(res + r0 * ld + (unsigned)(row * ld + 4 * c4))
                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV float4 prefetchc(int tile, int row, int c4) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);   // wave-uniform
+    return *reinterpret_cast<const float4*>(res + r0 * ld + (unsigned)((row < last ? row : last) * ld + 4 * c4));
   }
   DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x, const Cols& k) const {
     const int64_t r0 = (int64_t)tile * bm;

@@ -7,19 +7,27 @@
 #include <vector>
 __device__ unsigned long long* g_seg;
 #define GEMM_STAMP 1
-#define GEMM_STAMP_DECL unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
-#define GEMM_STAMP(i)                                                                                              \
-  do {                                                                                                             \
-    const unsigned long long n_ = __builtin_amdgcn_s_memtime();                                                    \
-    if ((threadIdx.x & 63) == 0) g_seg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] += n_ - t_last_;  \
-    t_last_ = n_;                                                                                                  \
+// per-wave accumulators in registers, written once at the end (a stamp costs one s_memtime + a 64-bit add)
+#define GEMM_STAMP_DECL                                   \
+  unsigned long long seg_[6] = {0, 0, 0, 0, 0, 0};       \
+  unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+#define GEMM_STAMP(i)                                                 \
+  do {                                                                \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime();       \
+    seg_[i] += n_ - t_last_;                                          \
+    t_last_ = n_;                                                     \
   } while (0)
 #define GEMM_STAMP_ACC(i, x)                             \
   do {                                                   \
     asm volatile("s_nop 15\n\ts_nop 15" ::"v"(x));        \
     GEMM_STAMP(i);                                       \
   } while (0)
+#define GEMM_STAMP_END                                                                                       \
+  if ((threadIdx.x & 63) == 0) {                                                                             \
+    for (int i_ = 0; i_ < 6; ++i_) g_seg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = seg_[i_];  \
+  }
 #include "gemm_ws.h"
+#include "backward.h"
 
 template <class Kern, class AL, class EP>
 void run(const char* name, Kern kern, size_t lds, int wgs, int ntiles, const float* W, int ldw, unsigned* queue, AL al, EP ep,
@@ -74,6 +82,34 @@ int main() {
     auto kern = gemm_ws_kernel<128, 3, 1, 4, ALoadDense, EpiBiasStore, false>;
     const size_t lds = GemmShape<128, 3, 1, 4>::lds_bytes(false);
     for (int wgs : {256}) run("K1 qkv", kern, lds, wgs, ntiles, W, N, queue, al, ep, seg);
+  }
+  {   // K6: ffn 256 -> 128 + LN, A = ReLU(h) columns
+    float* HC;
+    hipMalloc(&HC, (M + 32) * 256 * 4);
+    hipMemset(HC, 0, (M + 32) * 256 * 4);
+    float* W6;
+    hipMalloc(&W6, 128 * 256 * 4);
+    hipMemset(W6, 0, 128 * 256 * 4);
+    ALoadCols al{HC, M, 256, 0, 32, false};
+    EpiBiasResLN<32> ep{Y, bias, X, gam, bet, M, N, 32};
+    auto kern = gemm_ws_kernel<256, 1, 1, 4, ALoadCols, EpiBiasResLN<32>, false>;
+    const size_t lds = GemmShape<256, 1, 1, 4>::lds_bytes(false);
+    for (int wgs : {256}) run("K6 ffn + LN", kern, lds, wgs, ntiles, W6, 256, queue, al, ep, seg);
+  }
+  {   // K4: LSTM pre-activations 128 -> 2 x 512, sequence-tile rows, direct epilogue (one direction = one column group)
+    const int B = 8, S = 141, K = 150;
+    SeqGeom g = make_geom(0, B, S, K);
+    float *PRE, *W4, *b4;
+    const int nst16 = (g.nseq + 15) / 16;
+    hipMalloc(&PRE, (size_t)2 * g.nst * g.len * 16384 * 4);
+    hipMalloc(&W4, 1024 * 128 * 4); hipMemset(W4, 0, 1024 * 128 * 4);
+    hipMalloc(&b4, 1024 * 4); hipMemset(b4, 0, 1024 * 4);
+    ALoadSeqTile al{A, N, g};
+    EpiLstmPre16 ep{PRE, {b4, b4 + 512}, {b4, b4 + 512}, g, nst16};
+    auto kern = gemm_ws_kernel<128, 4, 1, 4, ALoadSeqTile, EpiLstmPre16, false>;
+    const size_t lds = GemmShape<128, 4, 1, 4>::lds_bytes(true);
+    // one column group only (the harness launches a 1-D grid): 256 workgroups over nst*len tiles
+    run("K4 lstm-pre (1 direction)", kern, lds, 256, g.nst * g.len, W4, N, queue, al, ep, seg);
   }
   return 0;
 }
