@@ -41,6 +41,12 @@ struct epi_has_cols : std::false_type {};
 template <class E>
 struct epi_has_cols<E, std::void_t<typename E::Cols>> : std::true_type {};
 struct EpiNoCols {};
+// DIRECT epilogues may offer `float direct_const(colgroup, cb, c)` (e.g. the scaled bias of the lane's column): loaded
+// once per workgroup and handed to store_acc instead of two dependent global loads per column block and tile.
+template <class E, class = void>
+struct has_direct_const : std::false_type {};
+template <class E>
+struct has_direct_const<E, std::void_t<decltype(std::declval<const E&>().direct_const(0, 0, 0))>> : std::true_type {};
 // Epilogues may opt in (static constexpr bool PIN_SCHEDULE = true) to the hand-pinned schedule of the N -> N kernels
 // (fragment batch in front of the MFMAs, two accumulation chains, prefetched operands held behind the MFMA block):
 // measured on the out-projection + LayerNorm kernel; other shapes were faster with the compiler's own schedule.
@@ -89,8 +95,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   float* Cs = As + 2 * Sh::BM * Sh::LDA;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
-  const int wr = wave / WC, wc = wave % WC;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;   // wave-uniform (scalar registers)
   const int colgroup = blockIdx.y;  // which WGCOLS-wide slice of NOUT
 
   // ---- weights -> B fragments, once ----------------------------------------------------------
@@ -145,6 +151,12 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   if constexpr (HOIST_COLS) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) ecols[p] = epi.cols(colgroup, (p * 256 + tid) % C4);
+  }
+
+  float dconst[NT];
+  if constexpr (Epi::DIRECT && has_direct_const<Epi>::value) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dconst[nt] = epi.direct_const(colgroup, wc * NT + nt, c);
   }
 
   unsigned* queue = tile_queue + colgroup;
@@ -254,7 +266,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     GEMM_STAMP_ACC(3, acc[NT - 1][15]);
     if constexpr (Epi::DIRECT) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (has_direct_const<Epi>::value) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh, dconst[nt]);
+        else epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
+      }
     } else {
       // ---- C tile -> LDS (each half-wave writes 128 B contiguous), then row-space epilogue ------
 #pragma unroll
@@ -463,13 +478,15 @@ struct EpiLstmPre {
   const float* b_ih[2];
   const float* b_hh[2];
   SeqGeom g;
-  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
-    const int st = tile / g.len, t = tile - st * g.len;
+  // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm.hip evaluates the activations without a
+  // multiply (cb >> 2 is the gate; the bias add became an fma)
+  DEV float direct_const(int d, int cb, int c) const {
     const int j = cb * 32 + c;
-    // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm.hip evaluates the activations
-    // without a multiply (cb >> 2 is the gate; the bias add became an fma)
+    return (b_ih[d][j] + b_hh[d][j]) * lstm_gate_scale(cb >> 2);
+  }
+  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh, float bias) const {
+    const int st = tile / g.len, t = tile - st * g.len;
     const float gs = lstm_gate_scale(cb >> 2);
-    const float bias = (b_ih[d][j] + b_hh[d][j]) * gs;
     float* base = pre + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)cb * 1024 + hh * 128 + c * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -496,22 +513,25 @@ struct EpiLstmPre16 {
   const float* b_hh[2];
   SeqGeom g;
   int nst16;
-  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
-    const int st = tile / g.len, t = tile - st * g.len;
+  // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm16.hip evaluates the activations without a
+  // multiply
+  DEV float direct_const(int d, int cb, int c) const {
     const int j = cb * 32 + c;
+    return (b_ih[d][j] + b_hh[d][j]) * l16_gate_scale(cb >> 2);
+  }
+  DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh, float bias) const {
+    const int st = tile / g.len, t = tile - st * g.len;
     const int gate = cb >> 2;
-    // gate rows leave pre-scaled by -log2(e) (i, f, o) or -2 log2(e) (g): lstm16.hip evaluates the activations
-    // without a multiply
     const float gs = l16_gate_scale(gate);
-    const float bias = (b_ih[d][j] + b_hh[d][j]) * gs;
+    // wave-uniform part of the address (tile, column block) + the lane's part
+    const int lane_off = (c >> 4) * 256 + (hh * 16 + (c & 15)) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int st16 = 2 * st + (q >> 1);
       if (st16 >= nst16) continue;   // a 16-sequence tile made of padding only
-      float* base = pre + pre16_tile_offset(d, st16, t, nst16, g.len) + (cb & 3) * 2048 + (2 * gate + (c >> 4)) * 256 +
-                    ((2 * (q & 1) + hh) * 16 + (c & 15)) * 4;
-      *reinterpret_cast<float4*>(base) = make_float4(fmaf(acc[4 * q + 0], gs, bias), fmaf(acc[4 * q + 1], gs, bias),
-                                                     fmaf(acc[4 * q + 2], gs, bias), fmaf(acc[4 * q + 3], gs, bias));
+      float* ubase = pre + pre16_tile_offset(d, st16, t, nst16, g.len) + (cb & 3) * 2048 + 2 * gate * 256 + (q & 1) * 128;
+      *reinterpret_cast<float4*>(ubase + lane_off) = make_float4(fmaf(acc[4 * q + 0], gs, bias), fmaf(acc[4 * q + 1], gs, bias),
+                                                                 fmaf(acc[4 * q + 2], gs, bias), fmaf(acc[4 * q + 3], gs, bias));
     }
   }
 };
