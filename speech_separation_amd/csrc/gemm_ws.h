@@ -41,6 +41,12 @@ struct epi_has_cols : std::false_type {};
 template <class E>
 struct epi_has_cols<E, std::void_t<typename E::Cols>> : std::true_type {};
 struct EpiNoCols {};
+// Row-space epilogues may request a SECOND per-row operand ahead of the MFMA block (`prefetch2`, clamped / branch-free
+// like prefetchc): a row operand loaded inside row() costs one exposed global round trip per pass.
+template <class E, class = void>
+struct has_prefetch2 : std::false_type {};
+template <class E>
+struct has_prefetch2<E, std::void_t<decltype(std::declval<const E&>().prefetch2(0, 0, 0))>> : std::true_type {};
 // DIRECT epilogues may offer `float direct_const(colgroup, cb, c)` (e.g. the scaled bias of the lane's column): loaded
 // once per workgroup and handed to store_acc instead of two dependent global loads per column block and tile.
 template <class E, class = void>
@@ -198,12 +204,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     if (next < ntiles) load_tile(next);
     // epilogue operands that do not depend on the product (residual rows ...) are requested now as well
     float4 epf[NPASS];
+    float4 epf2[has_prefetch2<Epi>::value ? NPASS : 1];
     if constexpr (!Epi::DIRECT) {
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
         const int idx = p * 256 + tid;
         if constexpr (has_prefetchc<Epi>::value) epf[p] = epi.prefetchc(tile, idx / C4, idx % C4);
         else epf[p] = epi.prefetch(tile, idx / C4, idx % C4);
+        if constexpr (has_prefetch2<Epi>::value) epf2[p] = epi.prefetch2(tile, idx / C4, idx % C4);
       }
     }
 
@@ -285,9 +293,15 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         const int idx = p * 256 + tid;
         const int row = idx / C4, c4 = idx % C4;
         const float4 v = *reinterpret_cast<const float4*>(&Cs[row * Sh::LDC + 4 * c4]);
-        if constexpr (HOIST_COLS) epi.row(tile, row, colgroup, c4, v, epf[p], ecols[p]);
-        else if constexpr (epi_has_cols<Epi>::value) epi.row(tile, row, colgroup, c4, v, epf[p], epi.cols(colgroup, c4));
-        else epi.row(tile, row, colgroup, c4, v, epf[p]);
+        if constexpr (has_prefetch2<Epi>::value) {
+          if constexpr (HOIST_COLS) epi.row(tile, row, colgroup, c4, v, epf[p], epf2[p], ecols[p]);
+          else if constexpr (epi_has_cols<Epi>::value) epi.row(tile, row, colgroup, c4, v, epf[p], epf2[p], epi.cols(colgroup, c4));
+          else epi.row(tile, row, colgroup, c4, v, epf[p], epf2[p]);
+        } else {
+          if constexpr (HOIST_COLS) epi.row(tile, row, colgroup, c4, v, epf[p], ecols[p]);
+          else if constexpr (epi_has_cols<Epi>::value) epi.row(tile, row, colgroup, c4, v, epf[p], epi.cols(colgroup, c4));
+          else epi.row(tile, row, colgroup, c4, v, epf[p]);
+        }
       }
     }
     GEMM_STAMP(5);
@@ -565,21 +579,25 @@ struct EpiAddMaskStore {
   int ldo;
   int bm;
   int wgcols;
-  DEV float4 prefetch(int tile, int row, int c4) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    if (addend == nullptr || r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4*>(addend + r * ldo + 4 * c4);   // (single column group only)
+  DEV int last_row(int64_t r0) const { return (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1); }   // wave-uniform
+  DEV float4 prefetch(int tile, int row, int c4) const {   // (single column group only when an addend / gate is given)
+    if (addend == nullptr) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = last_row(r0);
+    return *reinterpret_cast<const float4*>(addend + r0 * ldo + (unsigned)((row < last ? row : last) * ldo + 4 * c4));
   }
-  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 a) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    if (r >= M) return;
-    const int col = colgroup * wgcols + 4 * c4;
+  DEV float4 prefetch2(int tile, int row, int c4) const {   // the ReLU-mask source row
+    if (gate == nullptr) return make_float4(1.f, 1.f, 1.f, 1.f);
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = last_row(r0);
+    return *reinterpret_cast<const float4*>(gate + r0 * ldo + (unsigned)((row < last ? row : last) * ldo + 4 * c4));
+  }
+  DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 a, float4 g) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    if (r0 + row >= M) return;
     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    if (gate != nullptr) {
-      const float4 g = *reinterpret_cast<const float4*>(gate + r * ldo + col);
-      v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(out + r * ldo + col) = v;
+    v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+    *reinterpret_cast<float4*>(out + r0 * ldo + (unsigned)(row * ldo + colgroup * wgcols + 4 * c4)) = v;
   }
 };
 
@@ -601,26 +619,35 @@ struct EpiLNBackward {
   int ld;
   int bm;
   float4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};   // this thread's column sums (its c4 is fixed)
-  DEV float4 prefetch(int tile, int row, int c4) const {
-    const int64_t r = (int64_t)tile * bm + row;
-    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  struct Cols { float4 b, ga; };
+  DEV Cols cols(int /*colgroup*/, int c4) const {
+    return Cols{*reinterpret_cast<const float4*>(bias + 4 * c4), *reinterpret_cast<const float4*>(gamma + 4 * c4)};
   }
-  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) {
-    const int64_t r = (int64_t)tile * bm + row;
-    const bool ok = r < M;
-    const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  DEV int last_row(int64_t r0) const { return (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1); }   // wave-uniform
+  DEV float4 prefetch(int tile, int row, int c4) const {   // residual row (clamped: rows beyond M are never stored)
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = last_row(r0);
+    return *reinterpret_cast<const float4*>(res + r0 * ld + (unsigned)((row < last ? row : last) * ld + 4 * c4));
+  }
+  DEV float4 prefetch2(int tile, int row, int c4) const {   // incoming gradient row
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = last_row(r0);
+    return *reinterpret_cast<const float4*>(dout + r0 * ld + (unsigned)((row < last ? row : last) * ld + 4 * c4));
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x, float4 d, const Cols& k) {
+    const int64_t r0 = (int64_t)tile * bm;
+    const bool ok = r0 + row < M;
+    v.x += k.b.x; v.y += k.b.y; v.z += k.b.z; v.w += k.b.w;
     if (MODE == 0) { v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
     const float mu = group_sum<GROUP>((v.x + v.y) + (v.z + v.w)) * (1.0f / (4 * GROUP));
     const float dx = v.x - mu, dy = v.y - mu, dzz = v.z - mu, dw = v.w - mu;
     const float var = group_sum<GROUP>((dx * dx + dy * dy) + (dzz * dzz + dw * dw)) * (1.0f / (4 * GROUP));
     const float rstd = rsqrtf(var + 1e-5f);
     const float4 zn = make_float4(dx * rstd, dy * rstd, dzz * rstd, dw * rstd);
-    float4 d = ok ? *reinterpret_cast<const float4*>(dout + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);   // padded rows must not reach the column sums
     sg.x += d.x * zn.x; sg.y += d.y * zn.y; sg.z += d.z * zn.z; sg.w += d.w * zn.w;
     sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
-    const float4 g = make_float4(d.x * ga.x, d.y * ga.y, d.z * ga.z, d.w * ga.w);
+    const float4 g = make_float4(d.x * k.ga.x, d.y * k.ga.y, d.z * k.ga.z, d.w * k.ga.w);
     const float m1 = group_sum<GROUP>((g.x + g.y) + (g.z + g.w)) * (1.0f / (4 * GROUP));
     const float m2 = group_sum<GROUP>((g.x * zn.x + g.y * zn.y) + (g.z * zn.z + g.w * zn.w)) * (1.0f / (4 * GROUP));
     if (!ok) return;
@@ -629,7 +656,7 @@ struct EpiLNBackward {
     o.y = rstd * (g.y - m1 - zn.y * m2);
     o.z = rstd * (g.z - m1 - zn.z * m2);
     o.w = rstd * (g.w - m1 - zn.w * m2);
-    *reinterpret_cast<float4*>(dz + r * ld + 4 * c4) = o;
+    *reinterpret_cast<float4*>(dz + r0 * ld + (unsigned)(row * ld + 4 * c4)) = o;
   }
   // 256 threads = (256/GROUP) row lanes x GROUP column lanes: reduce the row lanes through LDS
   DEV void finish(float* smem, int tid) {
