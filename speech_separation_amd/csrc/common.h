@@ -10,6 +10,7 @@
 //     order as long as A and B agree.  This makes every fragment fetch a ds_read_b128 /
 //     global_load_dwordx4.
 #pragma once
+#include <cstdint>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -154,4 +155,17 @@ static inline SeqGeom make_geom(int mode, int B, int S, int K) {
 // float4, and one wave instruction moves 1 KiB contiguously.
 DEV int64_t pre_tile_offset(int d, int st, int t, int nst, int len) {
   return (((int64_t)d * nst + st) * len + t) * (int64_t)(512 * 32);
+}
+
+
+// Host helper: "done once per HIP device" flags for function attributes (hipFuncSetAttribute applies to the device
+// that is current; a process may drive several GPUs through several engines).  Up to 64 devices.
+struct PerDeviceOnce {
+  uint64_t mask = 0;
+  bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask >> dev) & 1u); }
+  void set(int dev) { if (dev >= 0 && dev < 64) mask |= (uint64_t)1 << dev; }
+};
+inline int current_hip_device() {
+  int d = 0;
+  return hipGetDevice(&d) == hipSuccess ? d : 0;
 }

@@ -130,6 +130,7 @@ struct dptnav_ctx {
   int stride;
   int dh;
   int num_cus = 256;
+  int device_id = 0;   // the HIP device that was current at dptnav_create
   std::vector<PathWeights> pw;   // [2*block + path], rebuilt by dptnav_bind_weights
 
   int fail(int code, const char* fmt, ...) {
@@ -331,10 +332,10 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
                     hipStream_t st, DropCfg drop) {
   auto kern = attention_kernel<DH, NKB>;
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
-  static bool ready = false;
-  if (!ready) {
+  static PerDeviceOnce ready;   // per instantiation and device
+  if (!ready.done(c->device_id)) {
     if (int rc = set_lds(c, kern, lds, "attention")) return rc;
-    ready = true;
+    ready.set(c->device_id);
   }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
@@ -376,7 +377,8 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
-  static int resident = 0;  // per instantiation
+  static int resident_dev[64] = {};  // per instantiation and device
+  int& resident = resident_dev[c->device_id & 63];
   if (resident == 0) {
     if (int rc = set_lds(c, kern, lds, what)) return rc;
     int per_cu = 0;
@@ -661,10 +663,10 @@ template <int NN, int KK, class YL, class XL>
 int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XL& xl, float* grad) {
   auto kern = wgrad_kernel<NN, KK, YL, XL>;
   const size_t lds = WgradShape<NN, KK>::lds_bytes();
-  static bool ready = false;
-  if (!ready) {
+  static PerDeviceOnce ready;
+  if (!ready.done(c->device_id)) {
     if (int rc = set_lds(c, kern, lds, what)) return rc;
-    ready = true;
+    ready.set(c->device_id);
   }
   const int grid = cap_grid(ntiles, br.pl.slab_wgs);
   float* slab = br.ws + br.pl.slab;
@@ -1058,7 +1060,8 @@ int dptnav_create(const dptnav_config* cfg, dptnav_handle* out) {
   {
     int devid = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess &&
+    if (hipGetDevice(&devid) == hipSuccess) c->device_id = devid;
+    if (hipGetDeviceProperties(&prop, devid) == hipSuccess &&
         prop.multiProcessorCount > 0)
       c->num_cus = prop.multiProcessorCount;
   }

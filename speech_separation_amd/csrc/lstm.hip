@@ -258,12 +258,13 @@ int lstm32_launch(bool stamp, bool save, bool relu, int nst, int ndir, void* str
   if (save) { kern = lstm_recurrence_kernel<false, true, false>; id = 0; }
   else if (stamp) { kern = relu ? lstm_recurrence_kernel<true, false, true> : lstm_recurrence_kernel<true, false, false>; id = 1 + relu; }
   else { kern = relu ? lstm_recurrence_kernel<false, false, true> : lstm_recurrence_kernel<false, false, false>; id = 3 + relu; }
-  static bool ready[5] = {};
-  if (!ready[id]) {
+  static PerDeviceOnce ready[5];
+  const int dev = current_hip_device();
+  if (!ready[id].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LSTM_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    ready[id] = true;
+    ready[id].set(dev);
   }
   hipLaunchKernelGGL(kern, dim3(nst, ndir), dim3(256), LSTM_LDS_BYTES, static_cast<hipStream_t>(stream), pre, whh_f, whh_b, hc,
                      ldh, dump_row, g, stamps, tape_gates, tape_c);

@@ -267,12 +267,13 @@ int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, con
     case 6: kern = lstm16_kernel<true, true, 11>; break;   // bare MFMA stream
     default: return (int)hipErrorInvalidValue;
   }
-  static bool ready[7][2] = {};
-  if (!ready[variant][relu]) {
+  static PerDeviceOnce ready[7][2];
+  const int dev = current_hip_device();
+  if (!ready[variant][relu].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)L16_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    ready[variant][relu] = true;
+    ready[variant][relu].set(dev);
   }
   hipLaunchKernelGGL(kern, dim3(nst16, ndir), dim3(256), L16_LDS_BYTES, static_cast<hipStream_t>(stream), pre, whh_f, whh_b,
                      hc, ldh, dump_row, g, nst16, stamps);

@@ -216,12 +216,13 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
 int lstm_bptt_launch(int nst, void* stream, const float* tape_gates, const float* tape_c, const float* whh_f,
                      const float* whh_b, const float* dh_up, int ldh, float* dg_out, int ldg, int dump_row,
                      const SeqGeom& g, float* bias_partials) {
-  static bool ready = false;
-  if (!ready) {
+  static PerDeviceOnce ready;
+  const int dev = current_hip_device();
+  if (!ready.done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPTT_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    ready = true;
+    ready.set(dev);
   }
   hipLaunchKernelGGL(lstm_bptt_kernel, dim3(nst, 2), dim3(256), BPTT_LDS_BYTES, static_cast<hipStream_t>(stream), tape_gates,
                      tape_c, whh_f, whh_b, dh_up, ldh, dg_out, ldg, dump_row, g, bias_partials);
