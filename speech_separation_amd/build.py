@@ -14,7 +14,10 @@ OUT = os.path.join(HERE, "libdptnav.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # translation units and their extra flags.  lstm.hip / lstm16.hip: MFMA accumulators in architectural VGPRs so that the 256 W_hh
 # fragments own the AGPRs and the step loop carries no v_accvgpr moves (see the file's header).
-SOURCES = {"dptnav.hip": [], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+# dptnav.hip: the GEMM engine's tile-ticket atomicAdd is issued by ONE lane a whole MFMA block before its result is used;
+# LLVM's atomic optimizer would turn it into a wave reduction + broadcast that waits for the result on the spot (wave 0
+# then sits out the round trip of a contended atomic every tile, the other waves wait for it at the next barrier).
+SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm_bptt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

@@ -186,17 +186,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   int buf = 0;
   GEMM_STAMP_DECL
   while (tile < ntiles) {
-    GEMM_STAMP(0);
     float* Ab = As + buf * (Sh::BM * Sh::LDA);
-    if (tid == 0) {                                            // publish the next ticket, request the one after it
-      s_next[buf ^ 1] = ticket_ahead;
-      ticket_ahead = (int)atomicAdd(queue, 1u);
-    }
+    if (tid == 0) s_next[buf ^ 1] = ticket_ahead;              // publish the next ticket (requested one tile ago)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
       *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
     }
+    GEMM_STAMP(0);     // (diagnostic builds: phase 0 = ticket + A tile -> LDS, phase 1 = the barrier)
     __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
     GEMM_STAMP(1);
 
@@ -215,6 +212,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       }
     }
 
+    // request the ticket after the next one HERE, in front of the MFMA block: issued at the loop top it was the youngest
+    // memory operation when the A-tile registers are waited for (s_waitcnt vmcnt(0)), i.e. wave 0 sat out the atomic's
+    // round trip every tile and the other waves waited for it at the barrier (~1 k cycles per tile)
+    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
     GEMM_STAMP(2);
     // ---- A fragments + MFMA --------------------------------------------------------------------
     f32x16 acc[NT];

@@ -29,6 +29,20 @@ __device__ unsigned long long* g_seg;
 #include "gemm_ws.h"
 #include "backward.h"
 
+// timing-only ablation: the LSTM pre-activation epilogue WITHOUT its global stores (is the A->LDS phase waiting for the
+// previous tile's stores to retire?)
+struct EpiLstmPre16NoStore : EpiLstmPre16 {
+  DEV void store_acc(int tile, int wr, int d, int cb, const f32x16& acc, int c, int hh, float bias) const {
+    const float gs = l16_gate_scale(cb >> 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(fmaf(acc[4 * q + 0], gs, bias), fmaf(acc[4 * q + 1], gs, bias), fmaf(acc[4 * q + 2], gs, bias),
+                             fmaf(acc[4 * q + 3], gs, bias));
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    }
+  }
+};
+
 template <class Kern, class AL, class EP>
 void run(const char* name, Kern kern, size_t lds, int wgs, int ntiles, const float* W, int ldw, unsigned* queue, AL al, EP ep,
          unsigned long long* seg) {
@@ -51,7 +65,7 @@ void run(const char* name, Kern kern, size_t lds, int wgs, int ntiles, const flo
   for (int w = 0; w < wgs * 4; ++w)
     for (int i = 0; i < 6; ++i) s[i] += (double)h[(size_t)w * 8 + i];
   const double per = (double)ntiles * 4;   // wave-tiles
-  printf("%-26s %4d WGs %.3f ms | cycles per tile and wave: loop-top %.0f  A->LDS+barrier %.0f  prefetch issue %.0f  frag+MFMA %.0f  "
+  printf("%-26s %4d WGs %.3f ms | cycles per tile and wave: ticket + A->LDS %.0f  barrier %.0f  prefetch issue %.0f  frag+MFMA %.0f  "
          "C->LDS+barrier %.0f  epilogue %.0f | sum %.0f\n",
          name, wgs, ms, s[0] / per, s[1] / per, s[2] / per, s[3] / per, s[4] / per, s[5] / per,
          (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / per);
@@ -110,6 +124,9 @@ int main() {
     const size_t lds = GemmShape<128, 4, 1, 4>::lds_bytes(true);
     // one column group only (the harness launches a 1-D grid): 256 workgroups over nst*len tiles
     run("K4 lstm-pre (1 direction)", kern, lds, 256, g.nst * g.len, W4, N, queue, al, ep, seg);
+    EpiLstmPre16NoStore ep2{{PRE, {b4, b4 + 512}, {b4, b4 + 512}, g, nst16}};
+    auto kern2 = gemm_ws_kernel<128, 4, 1, 4, ALoadSeqTile, EpiLstmPre16NoStore, false>;
+    run("K4 without its stores", kern2, lds, 256, g.nst * g.len, W4, N, queue, al, ep2, seg);
   }
   return 0;
 }
