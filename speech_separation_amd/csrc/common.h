@@ -112,12 +112,6 @@ struct DropCfg {
   float inv_keep;    // 1 / (1 - p)
 };
 
-// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to wave-uniform LDS base + lane*16 (no VGPR hop).
-DEV void glds16(const float* gsrc, float* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 // Sequence geometry of one TransformerDPRNN call over the token tensor x[b][s][k][n].
 //   mode 0 (intra-chunk): sequence q = b*S + s, position t = k   -> token q*K + t
 //   mode 1 (inter-chunk): sequence q = b*K + k, position t = s   -> token (b*S + t)*K + k
