@@ -89,6 +89,15 @@ struct dptnav_ctx {
   }
   hipStream_t streams[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
+  int ensure_sub_events(int n) {
+    while ((int)ev_sub.size() < n) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(DPTNAV_ERR_HIP, "event creation");
+      ev_sub.push_back(e);
+    }
+    return 0;
+  }
   int ensure_streams() {
     if (streams[0]) return 0;
     for (int i = 0; i < 2; ++i) {
@@ -1080,6 +1089,7 @@ void dptnav_destroy(dptnav_handle h) {
     if (h->ev_lstm[i]) hipEventDestroy(h->ev_lstm[i]);
   }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  for (hipEvent_t e : h->ev_sub) hipEventDestroy(e);
   delete h;
 }
 
@@ -1115,19 +1125,50 @@ int64_t dptnav_chunks(dptnav_handle h, int64_t T) {
   return h ? (dptnav_frames(h, T) - h->cfg.chunk_size) / h->cfg.step_size + 1 : -1;
 }
 
+// How dptnav_forward cuts a batch: sub-batches small enough that every recurrence launch fits the 16-sequence-tile kernel
+// in one round (2 * ceil(sequences / 16) <= CUs on both paths), as few of them as possible, at least two (the halves of
+// round 1) so that one sub-batch's recurrence always has another one's GEMM / attention kernels beside it.  Sequences
+// too long for that (fewer than 4 mixtures would fit) keep the plain two halves.
+constexpr int MAX_SUB = 32;
+static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes) {
+  if (!h->opt_overlap || B < 2) { sizes[0] = B; return 1; }
+  Plan pl;
+  int nsub = 2;
+  if (h->opt_lstm16 && make_plan(h, 1, T, Tv, &pl) == DPTNAV_OK) {
+    const int64_t S = pl.S, K = h->cfg.chunk_size;
+    const int ndir_inter = h->cfg.bidir ? 2 : 1;
+    auto fits = [&](int b) { return ((b * S + 15) / 16) * 2 <= h->num_cus && ((b * K + 15) / 16) * ndir_inter <= h->num_cus; };
+    int bfit = 0;
+    while (bfit < B && fits(bfit + 1)) ++bfit;
+    if (bfit >= 4) nsub = std::max(2, (B + bfit - 1) / bfit);
+  }
+  if (nsub > MAX_SUB) nsub = MAX_SUB;
+  if (nsub > B) nsub = B;
+  for (int i = 0; i < nsub; ++i) sizes[i] = B / nsub + (i < B % nsub ? 1 : 0);
+  return nsub;
+}
+
 size_t dptnav_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv) {
   if (!h) return 0;
-  // dptnav_forward (option overlap=1) splits B >= 2 into two independently planned halves; the stage entry
-  // points and overlap=0 use one plan for the whole batch.  The workspace covers whichever of the two is valid/larger.
+  // dptnav_forward (option overlap=1) runs B >= 2 as independently planned sub-batches; the stage entry points and
+  // overlap=0 use one plan for the whole batch.  The workspace covers whichever of the two is valid/larger.
   Plan pl;
   size_t need = 0;
   if (make_plan(h, B, T, Tv, &pl) == DPTNAV_OK) need = pl.total;
   if (B >= 2) {
-    Plan a, b;
-    if (make_plan(h, (B + 1) / 2, T, Tv, &a) == DPTNAV_OK && make_plan(h, B / 2, T, Tv, &b) == DPTNAV_OK) {
-      const size_t two = ((a.total + 63) & ~(size_t)63) + ((b.total + 63) & ~(size_t)63);
-      if (two > need) need = two;
+    const bool keep = h->opt_overlap;
+    h->opt_overlap = true;                       // size for the split even if the option is switched on later
+    int sizes[MAX_SUB];
+    const int nsub = forward_split(h, B, T, Tv, sizes);
+    h->opt_overlap = keep;
+    size_t sum = 0;
+    bool ok = true;
+    for (int i = 0; i < nsub && ok; ++i) {
+      Plan a;
+      ok = make_plan(h, sizes[i], T, Tv, &a) == DPTNAV_OK;
+      sum += (a.total + 63) & ~(size_t)63;
     }
+    if (ok && sum > need) need = sum;
   }
   return need * sizeof(float);
 }
@@ -1187,75 +1228,78 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   const bool big = h->cfg.num_features == 128;
   const dptnav_config& g = h->cfg;
 
-  // Mixtures are independent, so the batch is processed as two halves on two internal streams: the LSTM
-  // recurrence can only occupy 2 x ceil(sequences/32) CUs, and the other half's GEMM / attention launches
-  // (dynamic tile tickets) fill the rest of the chip meanwhile.  Fork/join by events on the caller's stream.
-  const int nhalf = (h->opt_overlap && B >= 2) ? 2 : 1;
-  int Bh[2] = {nhalf == 2 ? (B + 1) / 2 : B, nhalf == 2 ? B / 2 : 0};
-  Plan pl[2];
-  size_t need = 0, base[2] = {0, 0};
-  for (int i = 0; i < nhalf; ++i) {
-    if (int rc = make_plan(h, Bh[i], T, Tv, &pl[i])) return rc;
+  // Mixtures are independent, so the batch is processed as sub-batches on two internal streams (forward_split): a
+  // recurrence launch occupies one CU per (direction, 16-sequence tile), and the other stream's GEMM / attention
+  // launches (dynamic tile tickets) fill the rest of the chip meanwhile.  Fork/join by events on the caller's stream.
+  int Bs[MAX_SUB];
+  const int nsub = forward_split(h, B, T, Tv, Bs);
+  Plan pl[MAX_SUB];
+  size_t need = 0, base[MAX_SUB];
+  for (int i = 0; i < nsub; ++i) {
+    if (int rc = make_plan(h, Bs[i], T, Tv, &pl[i])) return rc;
     base[i] = need;
     need += (pl[i].total + 63) & ~(size_t)63;
   }
   if (ws_bytes < need * sizeof(float))
     return h->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need * sizeof(float));
-  if (nhalf == 2) {
+  if (nsub > 1) {
     if (int rc = h->ensure_streams()) return rc;
+    if (int rc = h->ensure_sub_events(nsub)) return rc;
     if (hipEventRecord(h->ev_fork, st) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork event");
+    for (int s = 0; s < 2; ++s)
+      if (hipStreamWaitEvent(h->streams[s], h->ev_fork, 0) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork wait");
   }
   const int64_t Cv = g.audio_only ? 0 : g.video_emb_size;
-  Run run[2];
-  const float *mixi[2], *e1i[2], *e2i[2];
-  float *s1i[2], *s2i[2];
-  for (int i = 0; i < nhalf; ++i) {
-    hipStream_t si = nhalf == 2 ? h->streams[i] : st;
-    if (nhalf == 2 && hipStreamWaitEvent(si, h->ev_fork, 0) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork wait");
-    const int64_t b0 = i == 0 ? 0 : Bh[0];
+  Run run[MAX_SUB];
+  const float *mixi[MAX_SUB], *e1i[MAX_SUB], *e2i[MAX_SUB];
+  float *s1i[MAX_SUB], *s2i[MAX_SUB];
+  int64_t b0 = 0;
+  for (int i = 0; i < nsub; ++i) {
+    hipStream_t si = nsub > 1 ? h->streams[i & 1] : st;   // sub-batches alternate between the two streams
     if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
     mixi[i] = mix + b0 * T;
     e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
     e2i[i] = e2 ? e2 + b0 * Cv * Tv : nullptr;
     s1i[i] = s1 + b0 * T;
     s2i[i] = s2 + b0 * T;
+    b0 += Bs[i];
   }
-  // The halves advance in lock step on the host, but their recurrences are chained by events
-  // (L(h0,p) -> L(h1,p) -> L(h0,p+1) ...): at any time at most ONE half sits in the LSTM (<= 76 CUs) while the
-  // other half's GEMM / attention kernels use the remaining CUs -- without the chain both halves reach the
+  // The sub-batches advance in lock step on the host, but their recurrences are chained by events
+  // (L(s0,p) -> L(s1,p) -> ... -> L(s0,p+1) ...): at any time at most ONE sub-batch sits in the LSTM while the
+  // other stream's GEMM / attention kernels use the remaining CUs -- without the chain the streams reach the
   // recurrence together and nothing is gained.
   auto E = [&](int i) { return run[i].ws + run[i].pl.E; };
   auto X0 = [&](int i) { return run[i].ws + run[i].pl.X0; };
   auto X1 = [&](int i) { return run[i].ws + run[i].pl.X1; };
-  for (int i = 0; i < nhalf; ++i) {
-    int rc = big ? run_head<128>(h, run[i], mixi[i], e1i[i], e2i[i], Bh[i], T, Tv, E(i), X0(i))
-                 : run_head<64>(h, run[i], mixi[i], e1i[i], e2i[i], Bh[i], T, Tv, E(i), X0(i));
+  for (int i = 0; i < nsub; ++i) {
+    int rc = big ? run_head<128>(h, run[i], mixi[i], e1i[i], e2i[i], Bs[i], T, Tv, E(i), X0(i))
+                 : run_head<64>(h, run[i], mixi[i], e1i[i], e2i[i], Bs[i], T, Tv, E(i), X0(i));
     if (rc) return rc;
   }
-  bool have_prev = false;
+  int prev = -1;
   for (int b = 0; b < g.num_blocks; ++b)
     for (int path = 0; path < 2; ++path)
-      for (int i = 0; i < nhalf; ++i) {
-        if (nhalf == 2) {
-          run[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
-          run[i].lstm_record = h->ev_lstm[i];
+      for (int i = 0; i < nsub; ++i) {
+        if (nsub > 1) {
+          run[i].lstm_wait = prev >= 0 ? h->ev_sub[prev] : nullptr;
+          run[i].lstm_record = h->ev_sub[i];
         }
         const float* xin = path == 0 ? X0(i) : X1(i);
         float* xout = path == 0 ? X1(i) : X0(i);
-        int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bh[i], (int)pl[i].S)
-                     : run_path<64>(h, run[i], b, path, xin, xout, Bh[i], (int)pl[i].S);
+        int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S)
+                     : run_path<64>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S);
         if (rc) return rc;
-        have_prev = true;
+        prev = i;
       }
-  for (int i = 0; i < nhalf; ++i) {
-    int rc = big ? run_tail<128>(h, run[i], X0(i), E(i), Bh[i], T, s1i[i], s2i[i])
-                 : run_tail<64>(h, run[i], X0(i), E(i), Bh[i], T, s1i[i], s2i[i]);
+  for (int i = 0; i < nsub; ++i) {
+    int rc = big ? run_tail<128>(h, run[i], X0(i), E(i), Bs[i], T, s1i[i], s2i[i])
+                 : run_tail<64>(h, run[i], X0(i), E(i), Bs[i], T, s1i[i], s2i[i]);
     if (rc) return rc;
-    if (nhalf == 2) {
-      if (hipEventRecord(h->ev_join[i], run[i].st) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess)
-        return h->fail(DPTNAV_ERR_HIP, "join event");
-    }
   }
+  if (nsub > 1)
+    for (int s = 0; s < 2; ++s)
+      if (hipEventRecord(h->ev_join[s], h->streams[s]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[s], 0) != hipSuccess)
+        return h->fail(DPTNAV_ERR_HIP, "join event");
   return DPTNAV_OK;
 }
 
