@@ -149,25 +149,20 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
     float4 hs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
-    // the wave's own LDS region may only be refilled once these reads have returned
+#ifdef L16_EXPLICIT_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // accumulators in architectural VGPRs (the cell update reads them with plain VALU instructions)
+#endif
+    // accumulators in architectural VGPRs (the cell update reads them with plain VALU instructions).  Their LDS reads
+    // were issued before the barrier: the wait the compiler puts here leaves the ten reads above in flight, and the
+    // first MFMAs start as soon as THEIR fragment has arrived (waiting for all of them up front cost ~100 cycles/step)
 #pragma unroll
     for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
-    // (without this pin the allocator tries the full AGPR half for these load results and spills them)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hs[j].x), "+v"(hs[j].y), "+v"(hs[j].z), "+v"(hs[j].w));
     if (STAMP) c1 = __builtin_amdgcn_s_memtime();
 
     // branch-free: the last step re-requests its own tile; step 0 stores the zeros of h_{-1} at position t0 without
     // advancing and step 1 overwrites them (same lane, same address, program order)
     const float* pnext = pre_lane + (int64_t)(step + 1 < g.len ? t + tdir : t) * L16_TILE_FLOATS;
     const unsigned adv = step > 0 ? sstep : 0u;
-    if (RELU) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        hs[j] = make_float4(relu1(hs[j].x), relu1(hs[j].y), relu1(hs[j].z), relu1(hs[j].w));
-    }
 
     // cell update of unit half hf (lane-local, two accumulator slots per call) + publish h_t
     auto cell_half = [&](int hf) {
@@ -207,6 +202,9 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
           // one memory instruction per MFMA group (issued back to back they stall the wave on the memory pipeline's
           // queue): slots 0, 1 the stores of h_{t-1}, slots 2..9 the LDS-DMA requests
           if (hf == 0 && slot < 2) {
+            // (the pin keeps the allocator from trying the full AGPR half for these load results and spilling them)
+            asm volatile("" : "+v"(hs[slot].x), "+v"(hs[slot].y), "+v"(hs[slot].z), "+v"(hs[slot].w));
+            if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
             if (!(DIAG & 2)) *reinterpret_cast<float4*>(hcb + soff[slot]) = hs[slot];
             soff[slot] += adv;
             __builtin_amdgcn_sched_barrier(0);
