@@ -72,9 +72,14 @@ struct WgradShape {
 };
 
 // grid.x workgroups; slab[blockIdx.x][NN][KK] receives the partial sum of this workgroup's tiles.
-template <int NN, int KK, class YLoad, class XLoad>
+constexpr int wgrad_gcd(int a, int b) { return b == 0 ? a : wgrad_gcd(b, a % b); }
+
+// COLSUM: the column sums of Y (= the bias gradient of the same layer) ride along: every thread adds up the float4s it
+// stages (their column is the same for every tile), the workgroup combines them in a fixed order at the end into
+// colslab[blockIdx.x][NN] -- instead of a second pass over Y by colsum_kernel.
+template <int NN, int KK, class YLoad, class XLoad, bool COLSUM = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __restrict__ queue, YLoad yl, XLoad xl,
-                                                     float* __restrict__ slab) {
+                                                     float* __restrict__ slab, float* __restrict__ colslab = nullptr) {
   using Sh = WgradShape<NN, KK>;
   static_assert(NN % 128 == 0 && KK % 32 == 0, "wgrad tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,6 +101,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   constexpr int NY = (32 * Y4) / 256, NX = (32 * X4) / 256;
   static_assert((32 * Y4) % 256 == 0 && (32 * X4) % 256 == 0, "staging map");
   float4 py[NY], px[NX];
+  // a thread's staging slot i holds column block (i*256 + tid) % Y4: NCS = Y4 / gcd(Y4, 256) distinct ones, visited
+  // round robin in i
+  constexpr int NCS = COLSUM ? Y4 / wgrad_gcd(Y4, 256) : 1;
+  float4 csum[NCS];
+#pragma unroll
+  for (int k = 0; k < NCS; ++k) csum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   int ticket_ahead = 0;
   if (tid == 0) {
     s_next[0] = (int)atomicAdd(queue, 1u);
@@ -116,6 +127,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
     for (int i = 0; i < NY; ++i) {
       const int idx = i * 256 + tid;
       *reinterpret_cast<float4*>(&Ys[(idx / Y4) * Sh::LDY + 4 * (idx % Y4)]) = py[i];
+      if constexpr (COLSUM) {
+        float4& a = csum[i % NCS];
+        a.x += py[i].x; a.y += py[i].y; a.z += py[i].z; a.w += py[i].w;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -160,6 +175,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         out[(size_t)((w + 4 * i) * 32 + ROW32(r, hh)) * KK + j * 32 + c] = acc[i][j][r];
+  if constexpr (COLSUM) {
+    // thread tid's accumulator k belongs to column block (k*256 + tid) % Y4; owner thread cb sums its contributors in
+    // (k, tid) order -- a fixed association order
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);   // [NCS][256] float4 (the tile buffers are free now)
+    static_assert(sizeof(float) * (4 + 32 * (size_t)(Sh::LDY + Sh::LDX)) >= sizeof(float4) * NCS * 256, "reduction scratch");
+#pragma unroll
+    for (int k = 0; k < NCS; ++k) red[k * 256 + tid] = csum[k];
+    __syncthreads();
+    if (tid < Y4) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < NCS; ++k)
+        for (int t2 = ((tid - k * 256) % Y4 + Y4) % Y4; t2 < 256; t2 += Y4) {   // (k*256 + t2) % Y4 == tid
+          const float4 u = red[k * 256 + t2];
+          a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+      *reinterpret_cast<float4*>(colslab + (size_t)blockIdx.x * NN + 4 * tid) = a;
+    }
+  }
 }
 
 // column sums over the rows of Y[M][ld] (columns [col0, col0+C)): slab[blockIdx.x][C]

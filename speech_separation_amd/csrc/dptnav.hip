@@ -667,23 +667,37 @@ struct BwdRun {
   }
 };
 
-// dW[NN][KK] = sum_tokens Y^T X  ->  grad (overwrite)
+// dW[NN][KK] = sum_tokens Y^T X  ->  grad (overwrite);  bias_grad (optional): column sums of Y, fused into the same pass
 template <int NN, int KK, class YL, class XL>
-int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XL& xl, float* grad) {
-  auto kern = wgrad_kernel<NN, KK, YL, XL>;
+int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XL& xl, float* grad,
+                 float* bias_grad = nullptr) {
   const size_t lds = WgradShape<NN, KK>::lds_bytes();
-  static PerDeviceOnce ready;
-  if (!ready.done(c->device_id)) {
-    if (int rc = set_lds(c, kern, lds, what)) return rc;
-    ready.set(c->device_id);
-  }
   const int grid = cap_grid(ntiles, br.pl.slab_wgs);
   float* slab = br.ws + br.pl.slab;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab);
+  float* colslab = slab + (size_t)grid * NN * KK;   // behind the weight slabs (BWD_SLAB_WGS x 512 x 128 floats in all)
+  if (bias_grad) {
+    auto kern = wgrad_kernel<NN, KK, YL, XL, true>;
+    static PerDeviceOnce ready;
+    if (!ready.done(c->device_id)) {
+      if (int rc = set_lds(c, kern, lds, what)) return rc;
+      ready.set(c->device_id);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab, colslab);
+  } else {
+    auto kern = wgrad_kernel<NN, KK, YL, XL, false>;
+    static PerDeviceOnce ready;
+    if (!ready.done(c->device_id)) {
+      if (int rc = set_lds(c, kern, lds, what)) return rc;
+      ready.set(c->device_id);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab, (float*)nullptr);
+  }
   LAUNCH_CHECK(c, what);
   const int64_t count = (int64_t)NN * KK;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count,
                      grad, 0);
+  if (bias_grad)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((NN + 31) / 32), dim3(256), 0, br.st, colslab, grid, (int64_t)NN, bias_grad, 0);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -743,11 +757,11 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   br.slot = run.slot;
   // 2. ffn parameter gradients
-  if (int rc = launch_colsum<N>(c, br, "d ffn bias", DZ, M, N, 0, G("ffn.1.bias"))) return rc;
   {
     ALoadCols yl{DZ, M, N, 0, 32, false};
     ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32, true};
-    if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
+    if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
+      return rc;
   }
   // 3. d h = (dz2 W_f) masked by the ReLU
   run.slot = br.slot;
@@ -808,11 +822,12 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   br.slot = run.slot;
   // 8. out-projection gradients and d att
-  if (int rc = launch_colsum<N>(c, br, "d out bias", DZ, M, N, 0, G("mha.out_proj.bias"))) return rc;
   {
     ALoadCols yl{DZ, M, N, 0, 32, false};
     ALoadDense xl{att, M, N, 32};
-    if (int rc = launch_wgrad<N, N>(c, br, "d out weight", ntiles, yl, xl, G("mha.out_proj.weight"))) return rc;
+    if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
+                                    G("mha.out_proj.bias")))
+      return rc;
   }
   run.slot = br.slot;
   {
@@ -856,11 +871,12 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     LAUNCH_CHECK(c, "attention bwd");
   }
   // 10. in-projection gradients and d x = dz1 (residual) + dqkv W_in
-  if (int rc = launch_colsum<3 * N>(c, br, "d in bias", DQKV, M, 3 * N, 0, G("mha.in_proj_bias"))) return rc;
   {
     ALoadCols yl{DQKV, M, 3 * N, 0, 32, false};
     ALoadDense xl{x_in, M, N, 32};
-    if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight", ntiles, yl, xl, G("mha.in_proj_weight"))) return rc;
+    if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight + bias", ntiles, yl, xl, G("mha.in_proj_weight"),
+                                        G("mha.in_proj_bias")))
+      return rc;
   }
   run.slot = br.slot;
   {
