@@ -137,18 +137,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
       const int idx = i * 256 + tid;
       *reinterpret_cast<float4*>(&Xs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = px[i];
     }
-    if (tid == 0) {
-      s_next[par ^ 1] = ticket_ahead;
-      ticket_ahead = (int)atomicAdd(queue, 1u);
-    }
+    if (tid == 0) s_next[par ^ 1] = ticket_ahead;   // publish the next ticket (requested one tile ago)
     __syncthreads();
-    const int next = s_next[par ^ 1];
+    const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
     if (next < ntiles) {
 #pragma unroll
       for (int i = 0; i < NY; ++i) py[i] = yl.load4(next, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
 #pragma unroll
       for (int i = 0; i < NX; ++i) px[i] = xl.load4(next, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
     }
+    // request the ticket after the next one here, in front of the MFMA block (as in gemm_ws.h: at the loop top it was
+    // the youngest memory operation when the staged registers are waited for)
+    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
     // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
