@@ -18,7 +18,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # LLVM's atomic optimizer would turn it into a wave reduction + broadcast that waits for the result on the spot (wave 0
 # then sits out the round trip of a contended atomic every tile, the other waves wait for it at the next barrier).
 SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-           "lstm_bptt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+           "lstm_bptt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "lstm_bptt16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _headers():

@@ -418,6 +418,16 @@ inline PathBufs inference_bufs(const Run& run) {
                   run.ws + run.pl.hc, nullptr, nullptr, false};
 }
 
+// K4/K5 tile height: 32 sequences per workgroup, or 16 when that still fits the chip in one round (sub-batch launches of
+// dptnav_forward, the halves of a split training batch): same CU-time, half the serial time of the recurrence.  The
+// training backward asks the same question (the tape layout follows the tile height).
+// (lstm16 addresses hc with 32-bit byte offsets: rows [0, M + S*K) x ldh floats)
+inline bool lstm_use16(const dptnav_ctx* c, const SeqGeom& geom, int ndir, int64_t M) {
+  const int nst16 = (geom.nseq + 15) / 16;
+  return c->opt_lstm16 && nst16 * ndir <= c->num_cus &&
+         (uint64_t)(M + (int64_t)geom.S * geom.K) * (uint64_t)(ndir * LSTM_H) * 4u < (1ull << 32);
+}
+
 // ---- one TransformerDPRNN (dptn.py:36-52) ---------------------------------------------------------
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
@@ -453,12 +463,8 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
     if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
   }
-  // K4/K5 tile height: 32 sequences per workgroup, or 16 when that still fits the chip in one round (half-batch
-  // launches of dptnav_forward): same CU-time, half the serial time of the recurrence (lstm16.h)
   const int nst16 = (geom.nseq + 15) / 16;
-  // (lstm16 addresses hc with 32-bit byte offsets: rows [0, M + S*K) x ldh floats)
-  const bool use16 = !pb.train && c->opt_lstm16 && nst16 * w.ndir <= c->num_cus &&
-                     (uint64_t)(M + (int64_t)geom.S * geom.K) * (uint64_t)(w.ndir * LSTM_H) * 4u < (1ull << 32);
+  const bool use16 = lstm_use16(c, geom, w.ndir, M);
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{lstm_in, N, geom};
@@ -478,12 +484,13 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
   if (use16) {
     // lstm_stamps: diagnostic builds; lstm_diag > 0 are timing-only ablations (wrong results), see lstm16.hip
-    const int variant = c->opt_lstm_stamps ? 1 + c->opt_lstm_diag : 0;
+    const int variant = pb.train ? L16_VARIANT_TRAIN : (c->opt_lstm_stamps ? 1 + c->opt_lstm_diag : 0);
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);   // room: nst16 <= 2 nst
     ProfScope ps(c, CAT_LSTM, st);
-    // DPTN feeds ffn = ReLU -> Linear (dptn.py:31); DPRNN feeds fc directly
-    const int rc = lstm16_launch(variant, c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                                 w.ndir * LSTM_H, (int)M, geom, stamps);
+    // DPTN inference stores ReLU(h) (ffn = ReLU -> Linear, dptn.py:31); training keeps raw h for the tape, DPRNN
+    // feeds fc directly
+    const int rc = lstm16_launch(variant, c->cfg.arch == 0 && !pb.train, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
+                                 w.ndir * LSTM_H, (int)M, geom, stamps, pb.gates, pb.cst);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16: %s", hipGetErrorString((hipError_t)rc));
   } else {
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
@@ -772,12 +779,16 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       return rc;
   }
   br.slot = run.slot;
-  // 4. LSTM backward through time
+  // 4. LSTM backward through time (tile height as in the forward that wrote the tape)
+  const bool use16 = lstm_use16(c, geom, 2, M);
+  const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;   // workgroups per direction = partial bias rows
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
   {
     ProfScope ps(c, CAT_LSTM, st);
-    const int rc = lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom,
-                                    LNP);
+    const int rc = use16 ? lstm_bptt16_launch(ntl, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M,
+                                              geom, LNP)
+                         : lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M,
+                                            geom, LNP);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
   }
   if (br.lstm_record && hipEventRecord(br.lstm_record, st) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger record");
@@ -787,9 +798,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
                       bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
     // bias gradients: per-workgroup partial rows written by the BPTT kernel
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * geom.nst * 512, geom.nst,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl,
                        (int64_t)512, G(bih.c_str()), 0);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * geom.nst * 512, geom.nst,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl,
                        (int64_t)512, G(bhh.c_str()), 0);
     LAUNCH_CHECK(c, "d lstm bias");
     ALoadDense xl{y1, M, N, 32};

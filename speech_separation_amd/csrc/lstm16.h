@@ -30,8 +30,11 @@ DEV int64_t pre16_tile_offset(int d, int st16, int t, int nst16, int len) {
   return (((int64_t)d * nst16 + st16) * len + t) * (int64_t)L16_TILE_FLOATS;
 }
 
-// Host-side launcher (lstm16.hip).  `variant`: 0 = product kernel; > 0 = diagnostic builds with per-wave s_memtime
-// stamps (1 = exact; 2.. = timing-only ablations with wrong results, see lstm16.hip).  hc byte offsets are 32-bit:
-// the caller guarantees (dump_row + max sequence extent) * ldh * 4 < 2^32.  Returns a hipError_t as int.
+// Host-side launcher (lstm16.hip).  `variant`: 0 = product kernel; 1..6 = diagnostic builds with per-wave s_memtime
+// stamps (1 = exact; 2.. = timing-only ablations with wrong results, see lstm16.hip); 7 = training forward (raw h,
+// gates and cell states kept on the tape for lstm_bptt16.hip).  hc byte offsets are 32-bit: the caller guarantees
+// (dump_row + max sequence extent) * ldh * 4 < 2^32.  Returns a hipError_t as int.
+constexpr int L16_VARIANT_TRAIN = 7;
 int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
-                  const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, unsigned long long* stamps);
+                  const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, unsigned long long* stamps,
+                  float* tape_gates = nullptr, float* tape_c = nullptr);

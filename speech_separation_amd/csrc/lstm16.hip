@@ -43,11 +43,18 @@ DEV float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 // STAMP: diagnostic build, per-wave s_memtime sums of [init, MFMA block (with the interleaved cell update), exposed
 // cell update, barrier] go to stamps[dir][tile][wave][4].  DIAG (timing-only ablations, results are wrong):
 // bit 0 no LDS-DMA, bit 1 no h stores, bit 3 identity activations.
-template <bool STAMP, bool RELU, int DIAG>
+// SAVE (training forward): the post-activation gates and the cell state of every step are kept for lstm_bptt16.hip, in
+// the fragment order of this kernel:
+//     tape_gates[d][st16][t][w][b = 2*gate + half][lane64][4]   (32 KiB per tile and step, = the PRE16 layout)
+//     tape_c    [d][st16][t][w][half][lane64][4]                ( 8 KiB per tile and step)
+// The ten 16-byte stores of a step ride between the NEXT step's first MFMA groups (one memory instruction per group).
+template <bool STAMP, bool RELU, int DIAG, bool SAVE = false>
 __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ pre, const float* __restrict__ whh_f,
                                                       const float* __restrict__ whh_b, float* __restrict__ hc, int ldh,
                                                       int dump_row, SeqGeom g, int nst16,
-                                                      unsigned long long* __restrict__ stamps) {
+                                                      unsigned long long* __restrict__ stamps,
+                                                      float* __restrict__ tape_gates = nullptr,
+                                                      float* __restrict__ tape_c = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                     // [2][16][L16_LDH]
   float* Ps = smem + L16_HS_FLOATS;     // [4][8][256]
@@ -133,6 +140,19 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
   };
   preload_acc();
 
+  f32x4v sv[SAVE ? 8 : 1];   // gates of the step just finished, block order b = 2*gate + half (SAVE only)
+  auto save_piece = [&](int piece, int tpos) {   // piece 0..7: gate block, 8..9: cell state of half piece - 8
+    const int64_t tile = pre16_tile_offset(d, st, tpos, nst16, g.len);
+    if (piece < 8) {
+      *reinterpret_cast<float4*>(tape_gates + tile + (int64_t)w * 2048 + piece * 256 + lane * 4) =
+          make_float4(sv[piece][0], sv[piece][1], sv[piece][2], sv[piece][3]);
+    } else {
+      const int hf = piece - 8;
+      *reinterpret_cast<float4*>(tape_c + tile / 4 + (int64_t)w * 512 + hf * 256 + lane * 4) =
+          make_float4(cst[hf][0], cst[hf][1], cst[hf][2], cst[hf][3]);
+    }
+  };
+
   unsigned long long seg[4] = {0, 0, 0, 0};
   for (int step = 0; step < g.len; ++step) {
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -178,6 +198,12 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
                                          (f32x2){acc[6 + hf][r], acc[6 + hf][r + 1]}, (f32x2){cst[hf][r], cst[hf][r + 1]});
           cst[hf][r] = u.c.x;
           cst[hf][r + 1] = u.c.y;
+          if constexpr (SAVE) {
+            sv[0 + hf][r] = u.i.x; sv[0 + hf][r + 1] = u.i.y;
+            sv[2 + hf][r] = u.f.x; sv[2 + hf][r + 1] = u.f.y;
+            sv[4 + hf][r] = u.g.x; sv[4 + hf][r + 1] = u.g.y;
+            sv[6 + hf][r] = u.o.x; sv[6 + hf][r + 1] = u.o.y;
+          }
           h0 = u.h.x;
           h1 = u.h.y;
         }
@@ -211,6 +237,9 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
           } else if (hf == 0 && slot < 10) {
             if (!(DIAG & 1)) issue_pre_piece(pnext, slot - 2);
             __builtin_amdgcn_sched_barrier(0);
+          } else if (SAVE && hf == 0 && slot < 20) {
+            if (step > 0) save_piece(slot - 10, t - tdir);   // the previous step's gates / cell state
+            __builtin_amdgcn_sched_barrier(0);
           } else if (hf == 1) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
@@ -235,6 +264,10 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
       seg[3] += c4 - c3;
     }
   }
+  if constexpr (SAVE) {
+#pragma unroll
+    for (int piece = 0; piece < 10; ++piece) save_piece(piece, t0 + tdir * (g.len - 1));
+  }
   // h of the last step: the barrier above published it in buffer (len & 1)
   {
     const float* hfin = Hs + (g.len & 1) * 16 * L16_LDH;
@@ -252,8 +285,10 @@ __global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ p
 }
 
 int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
-                  const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, unsigned long long* stamps) {
-  using Kern = void (*)(const float*, const float*, const float*, float*, int, int, SeqGeom, int, unsigned long long*);
+                  const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, unsigned long long* stamps,
+                  float* tape_gates, float* tape_c) {
+  using Kern = void (*)(const float*, const float*, const float*, float*, int, int, SeqGeom, int, unsigned long long*, float*,
+                        float*);
   Kern kern;
   switch (variant) {
     case 0: kern = relu ? lstm16_kernel<false, true, 0> : lstm16_kernel<false, false, 0>; break;
@@ -263,9 +298,11 @@ int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, con
     case 4: kern = lstm16_kernel<true, true, 3>; break;    // neither
     case 5: kern = lstm16_kernel<true, true, 8>; break;    // identity activations
     case 6: kern = lstm16_kernel<true, true, 11>; break;   // bare MFMA stream
+    case 7: kern = lstm16_kernel<false, false, 0, true>; break;   // training forward: raw h + tape
     default: return (int)hipErrorInvalidValue;
   }
-  static PerDeviceOnce ready[7][2];
+  if (variant == 7 && (!tape_gates || !tape_c)) return (int)hipErrorInvalidValue;
+  static PerDeviceOnce ready[8][2];
   const int dev = current_hip_device();
   if (!ready[variant][relu].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -274,6 +311,6 @@ int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, con
     ready[variant][relu].set(dev);
   }
   hipLaunchKernelGGL(kern, dim3(nst16, ndir), dim3(256), L16_LDS_BYTES, static_cast<hipStream_t>(stream), pre, whh_f, whh_b,
-                     hc, ldh, dump_row, g, nst16, stamps);
+                     hc, ldh, dump_row, g, nst16, stamps, tape_gates, tape_c);
   return (int)hipGetLastError();
 }

@@ -70,8 +70,9 @@ def test_path_backward_matches_autograd(dev, path):
         assert O.agreement_db(got, gref.numpy()) > 70, (leaf, O.agreement_db(got, gref.numpy()))
 
 
+@pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
 @pytest.mark.parametrize("audio_only", [False, True])
-def test_whole_model_backward_matches_autograd(dev, audio_only):
+def test_whole_model_backward_matches_autograd(dev, audio_only, lstm_tile):
     """d loss / d every parameter for a 2-block model: libdptnav train_forward/backward vs torch.autograd (fp64, CPU)."""
     from speech_separation_amd.engine import DptnEngine, params_to_device
     from speech_separation_amd.spec import synthetic_inputs
@@ -80,6 +81,7 @@ def test_whole_model_backward_matches_autograd(dev, audio_only):
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(sd, dev))
     grads = eng.bind_grads()
+    eng.set_option("lstm16", 1 if lstm_tile == 16 else 0)
     B, T, Tv = 2, 2000, 9
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=6)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
