@@ -396,9 +396,8 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          float dpv = dp[r0 + r];
-          if (drop.thresh != 0u)
-            dpv = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dpv * drop.inv_keep : 0.f;
+          // (straight-line: thresh = 0 / inv_keep = 1 without dropout)
+          const float dpv = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dp[r0 + r] * drop.inv_keep : 0.f;
           const float ds = s[rb][r0 + r] * inv * (dpv - delta);
           dq = mfma32(ds, kk[r], dq);
         }
@@ -471,9 +470,11 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         const int qrow_i = qb * 32 + ROW32(r, hh);
         const float4 st4 = St[qrow_i];
         const float pm = st4.x, pl = st4.y, pe = st4.z;
-        const float p2 = key_ok ? fast_exp2(s2[r] * sl2e - pm) * pl : 0.f;
-        float keep = 1.f;
-        if (drop.thresh != 0u) keep = drop_rand_q(__float_as_uint(st4.w), (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
+        // straight-line on purpose (selects, no branches): with a branch per element the compiler serialised the sixteen
+        // LDS round trips of a tile.  Without dropout thresh = 0 and inv_keep = 1: every element is "kept".
+        const float pexp = fast_exp2(s2[r] * sl2e - pm) * pl;
+        const float p2 = key_ok ? pexp : 0.f;
+        const float keep = drop_rand_q(__float_as_uint(st4.w), (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
         s2[r] = p2 * keep;                          // dropped P (feeds dV)
         dp2[r] = p2 * (dp2[r] * keep - pe);         // dS
         const float qv = Qs[qrow_i * LD + (c < DH ? c : 0)], dv_ = Ds[qrow_i * LD + (c < DH ? c : 0)];
