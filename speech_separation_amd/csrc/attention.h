@@ -32,7 +32,8 @@ struct AttnShape {
 template <int DH, int NKB>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_kernel(const float* __restrict__ qkv,
                                                               float* __restrict__ out, int N, int heads, SeqGeom g,
-                                                              float scale_log2e, DropCfg drop) {
+                                                              float scale_log2e, DropCfg drop,
+                                                              float2* __restrict__ stats_out = nullptr) {
   using Sh = AttnShape<DH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                        // [NKB*32][LDK]
@@ -130,6 +131,10 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     }
   sum += __shfl_xor(sum, 32);
   const float inv = fast_rcp(sum);
+  // training forward: the softmax statistics of every query (row max in the log2 domain, 1 / row sum) go to the tape;
+  // with them the backward handles one key block at a time instead of keeping the whole score row in registers
+  if (stats_out != nullptr && hh == 0 && qb * 32 + c < len)
+    stats_out[(tok0 + (int64_t)(qb * 32 + c) * tstride) * heads + head] = make_float2(mx, inv);
   if (drop.thresh != 0u) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
     const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)heads + (uint32_t)head);
 #pragma unroll

@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
                                                                   const float* __restrict__ att,
                                                                   const float* __restrict__ datt,
                                                                   float* __restrict__ dqkv, float* __restrict__ stats,
-                                                                  int heads, int N, SeqGeom g, float scale, DropCfg drop) {
+                                                                  int heads, int N, SeqGeom g, float scale, DropCfg drop,
+                                                                  const float2* __restrict__ fstats = nullptr) {
   using Sh = AttnBwdShape<DH>;
   constexpr int LD = Sh::LD, ROWS = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -333,61 +334,37 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
       }
     }
     const float delta = dsum + __shfl_xor(dsum, 32);
-    f32x16 s[NKB];
-#pragma unroll
-    for (int rb = 0; rb < NKB; ++rb) {
-      s[rb] = zero16();
-      const float* krow = Ks + (rb * 32 + c) * LD + 4 * hh;
-#pragma unroll
-      for (int m = 0; m < DH / 8; ++m) {
-        const float4 k = *reinterpret_cast<const float4*>(krow + 8 * m);
-        s[rb] = mfma32(k.x, qf[4 * m + 0], s[rb]);
-        s[rb] = mfma32(k.y, qf[4 * m + 1], s[rb]);
-        s[rb] = mfma32(k.z, qf[4 * m + 2], s[rb]);
-        s[rb] = mfma32(k.w, qf[4 * m + 3], s[rb]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if ((NKB - 1) * 32 + ROW32(r, hh) >= len) s[NKB - 1][r] = -1e30f;
-    float mx = -1e30f;
-#pragma unroll
-    for (int rb = 0; rb < NKB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[rb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < NKB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = fast_exp2(s[rb][r] - mx);
-        s[rb][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+    // softmax statistics of this lane's query, from the training forward's tape (attention.h): one key block at a time
+    // is enough then -- S^T tile, dP^T tile, dS, dQ -- instead of the whole score row (80 registers less)
+    float2 ms = make_float2(0.f, 0.f);
+    if (p < len) ms = fstats[(tok0 + (int64_t)p * tstride) * heads + head];
+    const float mx = ms.x, inv = ms.y;
     // per-query dropout seed: used here and handed to phase B with the statistics
     const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head);
     if (hh == 0 && p < len)
       *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) =
           make_float4(mx, inv, delta, __uint_as_float(qseed));
-    // dS^T tile by tile, then dQ = scale * dS K
     f32x16 dq = zero16();
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb) {
-      f32x16 dp = zero16();
+      f32x16 sc = zero16(), dp = zero16();
+      const float* krow = Ks + (rb * 32 + c) * LD + 4 * hh;
       const float* vrow = Vs + (rb * 32 + c) * LD + 4 * hh;
 #pragma unroll
       for (int m = 0; m < DH / 8; ++m) {
+        const float4 k = *reinterpret_cast<const float4*>(krow + 8 * m);
         const float4 v = *reinterpret_cast<const float4*>(vrow + 8 * m);
+        sc = mfma32(k.x, qf[4 * m + 0], sc);
         dp = mfma32(v.x, df[4 * m + 0], dp);
+        sc = mfma32(k.y, qf[4 * m + 1], sc);
         dp = mfma32(v.y, df[4 * m + 1], dp);
+        sc = mfma32(k.z, qf[4 * m + 2], sc);
         dp = mfma32(v.z, df[4 * m + 2], dp);
+        sc = mfma32(k.w, qf[4 * m + 3], sc);
         dp = mfma32(v.w, df[4 * m + 3], dp);
       }
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += 8) {      // K rows fetched 8 at a time (register budget: 3 waves per SIMD)
+      for (int r0 = 0; r0 < 16; r0 += 8) {      // K rows fetched 8 at a time
         float kk[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -396,10 +373,12 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          // (straight-line: thresh = 0 / inv_keep = 1 without dropout)
-          const float dpv = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r0 + r, hh))) >= drop.thresh ? dp[r0 + r] * drop.inv_keep : 0.f;
-          const float ds = s[rb][r0 + r] * inv * (dpv - delta);
-          dq = mfma32(ds, kk[r], dq);
+          const int key = rb * 32 + ROW32(r0 + r, hh);
+          // (straight-line: padded keys by select; thresh = 0 / inv_keep = 1 without dropout)
+          float pr = fast_exp2(sc[r0 + r] - mx) * inv;
+          if (rb == NKB - 1) pr = key < len ? pr : 0.f;
+          const float dpv = drop_rand_q(qseed, (uint32_t)key) >= drop.thresh ? dp[r0 + r] * drop.inv_keep : 0.f;
+          dq = mfma32(pr * (dpv - delta), kk[r], dq);
         }
       }
     }

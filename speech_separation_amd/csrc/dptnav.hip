@@ -338,7 +338,7 @@ inline int cap_grid(int64_t ntiles, int cap) { return (int)(ntiles < cap ? ntile
 // ---- attention dispatch over the number of 32-key blocks ----------------------------------------
 template <int DH, int NKB>
 int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads,
-                    hipStream_t st, DropCfg drop) {
+                    hipStream_t st, DropCfg drop, float2* stats) {
   auto kern = attention_kernel<DH, NKB>;
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
   static PerDeviceOnce ready;   // per instantiation and device
@@ -348,22 +348,22 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
   }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
-  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, heads, g, scale, drop);
+  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, heads, g, scale, drop, stats);
   LAUNCH_CHECK(c, "attention");
   return DPTNAV_OK;
 }
 template <int DH>
 int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads, hipStream_t st,
-                DropCfg drop = DropCfg{0u, 0u, 1.0f}) {
+                DropCfg drop = DropCfg{0u, 0u, 1.0f}, float2* stats = nullptr) {
   switch ((g.len + 31) / 32) {
-    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st, drop);
-    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st, drop);
-    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st, drop);
-    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st, drop);
-    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st, drop);
-    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st, drop);
-    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop);
-    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop);
+    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop, stats);
   }
   // longer sequences (inter-chunk path of utterances beyond ~7 s): streaming-softmax kernel, inference only
   if (drop.thresh != 0u) return c->fail(DPTNAV_ERR_INVALID, "attention: dropout needs sequence length <= 256 (got %d)", g.len);
@@ -412,6 +412,7 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
 struct PathBufs {
   float *qkv, *att, *y1, *pre, *hc, *gates, *cst;
   bool train;
+  float* astats = nullptr;   // training: where the attention forward leaves its softmax statistics
 };
 inline PathBufs inference_bufs(const Run& run) {
   return PathBufs{run.ws + run.pl.qkv, run.ws + run.pl.att, run.ws + run.pl.y1, run.ws + run.pl.pre,
@@ -456,7 +457,9 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (dptn)
-    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train, run.half))) return rc;
+    if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train, run.half),
+                                 reinterpret_cast<float2*>(pb.astats)))
+      return rc;
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
   if (dptn) {
     ALoadDense al{att, M, N, BM};
@@ -604,7 +607,7 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
 // training step, path level (BASELINE config 4): forward with a tape, backward from the tape
 // =================================================================================================
 struct PathTape {  // offsets in floats inside one path's tape
-  size_t qkv, att, y1, hc, gates, cst, total;
+  size_t qkv, att, y1, hc, gates, cst, astats, total;   // astats: softmax (max, 1/sum) per (token, head)
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
@@ -626,6 +629,7 @@ int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
   t->hc = take((size_t)(M + S * K) * 2 * H);
   t->gates = take((size_t)2 * nst * 512 * 32);
   t->cst = take((size_t)2 * nst * 128 * 32);
+  t->astats = take((size_t)M * g.num_heads * 2);
   t->total = o;
   return DPTNAV_OK;
 }
@@ -861,9 +865,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       ProfScope ps(c, CAT_ATTN, st);
       const DropCfg drop = c->drop_cfg(block, path, true, br.half);
       hipLaunchKernelGGL(kern0, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale, drop);
+                         geom, scale, drop, reinterpret_cast<const float2*>(tape + tp.astats));
       hipLaunchKernelGGL(kern1, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale, drop);
+                         geom, scale, drop, (const float2*)nullptr);
       return DPTNAV_OK;
     };
     int rc = DPTNAV_OK;
@@ -1397,7 +1401,7 @@ int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float*
   Run run;
   if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
   float* tb = (float*)tape;
-  PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true};
+  PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true, tb + tp.astats};
   return run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb);
 }
 int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
@@ -1538,7 +1542,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
       }
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
       PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run[i].ws + sp.pl[i].pre, pt + mt.pt.hc, pt + mt.pt.gates,
-                  pt + mt.pt.cst, true};
+                  pt + mt.pt.cst, true, pt + mt.pt.astats};
       if (int rc = run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
                                  tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb))
         return rc;
