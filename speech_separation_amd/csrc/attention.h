@@ -156,6 +156,10 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     float vv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) vv[r] = vcol[(rb * 32 + (r & 3) + 8 * (r >> 2)) * Sh::LDV];
+    // one wait for the whole batch, and MFMAs kept behind it: left alone the compiler pairs every two MFMAs with their
+    // own LDS read and waits for it there (40 exposed round trips per wave)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o = mfma32(vv[r], s[rb][r], o);
   }
