@@ -3,7 +3,8 @@
 //   wgrad_kernel     dW[NN][KK] = sum over tokens  dY[m][0:NN]^T  X[m][0:KK]     (a GEMM whose K dimension is the
 //                    3.4e5 tokens and whose output is tiny): every workgroup accumulates its share of 32-token tiles
 //                    in MFMA accumulators and writes ONE partial tile to a slab; slab_reduce_kernel sums the slabs in
-//                    a fixed order -> bit-reproducible, no float atomics.
+//                    a fixed order; no float atomics.  (Tiles are handed out by dynamic tickets: WHICH workgroup sums
+//                    which tiles varies between runs, so results agree to fp32 summation order, not bit for bit.)
 //   colsum_kernel    bias gradients: column sums of dY over the tokens, same slab scheme.
 #pragma once
 #include "lstm_bptt.h"
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y
   }
 }
 
-// out[i] (+)= sum_s slab[s][i] in a FIXED association order (bit-reproducible): a block owns 32 consecutive elements,
+// out[i] (+)= sum_s slab[s][i] in a FIXED association order: a block owns 32 consecutive elements,
 // its 8 slab-lanes each sum the slabs s = lane, lane+8, ... with four loads in flight, then the lanes are combined in
 // lane order.  (A single thread walking all slabs serially was latency-bound: ~10 % of the training step.)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nslabs, int64_t count,

@@ -1439,7 +1439,7 @@ static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, Mod
 // "train_overlap"): the LSTM forward and BPTT launches fill 57 % of the CUs at B = 16, and the other half's GEMM /
 // attention / weight-gradient kernels take the rest.  Each half has its own tape slice and workspace slice; the second
 // half writes its parameter gradients to scratch buffers in its workspace slice and ONE launch adds them to the bound
-// gradients at the end (fixed order: bit-reproducible).
+// gradients at the end (fixed order).
 struct TrainSplit {
   int nhalf;
   int Bh[2];

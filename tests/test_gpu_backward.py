@@ -255,3 +255,43 @@ def test_split_training_step_equals_unsplit(dev):
     assert O.agreement_db(a1, b1) > 110 and O.agreement_db(a2, b2) > 110
     worst = min((O.agreement_db(ga[k], gb[k]), k) for k in ga)
     assert worst[0] > 90, worst
+
+
+def test_full_size_training_step_is_deterministic(dev):
+    """B=16, T=32000 (BASELINE config 4, dropout 0.1): two forward/backward passes with the same dropout seed give
+    bit-identical outputs; the parameter gradients agree to fp32 summation order (the token reductions hand their tiles
+    out by dynamic tickets, so WHICH workgroup sums which tiles -- not the values summed -- varies from run to run; no
+    float atomics anywhere), and everything is finite."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import synthetic_inputs
+    cfg = DPTN_AV
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(synthetic_state_dict(cfg, seed=0), dev))
+    grads = eng.bind_grads()
+    eng.set_option("dropout_ppm", 100000)
+    eng.set_option("dropout_seed", 2024)
+    B, T = 16, 32000
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=3)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    d1 = torch.randn(B, T, generator=g).to(dev)
+    d2 = torch.randn(B, T, generator=g).to(dev)
+    runs = []
+    for _ in range(2):
+        s1, s2, tape = eng.train_forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
+        eng.train_backward(t["mix"], t["s1_embedding"], t["s2_embedding"], d1, d2, tape)
+        torch.cuda.synchronize()
+        runs.append((s1.clone(), s2.clone(), eng._grads_flat.clone()))
+        del tape
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    ga, gb = runs[0][2].double(), runs[1][2].double()
+    db = 10 * torch.log10(ga.pow(2).sum() / (ga - gb).pow(2).sum().clamp_min(1e-300))
+    assert float(db) > 110, float(db)
+    # per parameter as well (a race would show up as a large error in one tensor)
+    for k, g in eng._grads.items():
+        o = eng._grad_offsets[k]
+        a, b = ga[o:o + g.numel()], gb[o:o + g.numel()]
+        if float(a.pow(2).sum()) > 0:
+            assert float(10 * torch.log10(a.pow(2).sum() / (a - b).pow(2).sum().clamp_min(1e-300))) > 90, k
+    assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][2]).all()
+    assert float(runs[0][2].abs().max()) > 0.0
