@@ -122,17 +122,36 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
                       + "; ".join(parts) + "; max over B reported"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU (importing torch does not
+    initialise HIP), so it starts the N ranks as fresh children through torch.distributed.run -- one process per GPU,
+    rendezvous on 127.0.0.1 -- lets them inherit stdout/stderr (rank 0 prints the JSON line) and returns their exit
+    code.  Never an exec of a process that holds the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"launching {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def bench_train(args, env, cfg, B, T, workload):
-    """BASELINE configs[3]: one optimizer step per bench step (zero_grad, forward with tape, torch loss, HIP backward,
-    one flat-bucket RCCL all-reduce of the 17.8 MB of gradients when N > 1, clip, AdamW)."""
+    """BASELINE configs[3]: one optimizer step per bench step (zero_grad, forward with tape, device PIT SI-SNR loss, HIP
+    backward, one flat-bucket RCCL all-reduce of the 17.8 MB of gradients when N > 1, device clip + AdamW); nothing in
+    the step synchronises with the host (loss / gradient norm are read once, after the timed region)."""
     from speech_separation_amd import DPTNAVWavEncDec
-    from speech_separation_amd.train import SiSNRWavLoss, train_step
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
     dev = env.device
     kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}   # dropout 0.1 as in dptn_wav_av.yaml
     model = DPTNAVWavEncDec(**kw)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
     model = model.to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)     # dptn_wav_av.yaml:9-11 (AdamW, lr 1e-3, torch defaults)
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123 + env.rank)
     batch0 = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     crit = SiSNRWavLoss()
@@ -173,7 +192,8 @@ def bench_train(args, env, cfg, B, T, workload):
                          "frac": round(value / env.world * flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "note": "algorithmic FLOPs = 3 x forward (612 GFLOP per mixture)"},
             "kernels_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in prof.items()},
-            "last_step": stats}), flush=True)
+            "last_step": {k: round(float(v), 5) for k, v in stats.items()} if stats else None,
+            "host_syncs_per_step": 0}), flush=True)
     env.close()
 
 
@@ -187,6 +207,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="mixtures per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
 
     # BENCH_REHEARSAL=1: N ranks share cuda:0 and talk over gloo -- a rehearsal of the N > 1 code path on a one-GPU box
     # (its numbers mean nothing); the real launch is one rank per GPU over RCCL
@@ -314,4 +336,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DPTNAV_ABI_VERSION 2
+#define DPTNAV_ABI_VERSION 3
 
 /* error codes */
 #define DPTNAV_OK 0
@@ -153,7 +153,8 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
                                size_t bwd_workspace_bytes, void* stream);
 
 /* ---- training step, whole model ------------------------------------------------------------------------------
- * dptnav_train_forward  = dptnav_forward that records the tape (single stream, no half-batch overlap);
+ * dptnav_train_forward  = dptnav_forward that records the tape (a batch >= 2 runs as two halves on the two internal
+ *   streams like dptnav_forward: option "train_overlap", default 1);
  * dptnav_train_backward = everything torch.autograd would do for the model part of loss.backward()
  *   (src/trainer/trainer.py:47): given d loss / d s1_pred and d loss / d s2_pred it WRITES the gradient of every
  *   parameter into the buffers bound with dptnav_bind_grads.  The loss itself (src/loss/ss_losses.py), gradient
@@ -167,6 +168,35 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
 int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, const float* e2, const float* d_s1_pred,
                           const float* d_s2_pred, int B, int64_t T, int Tv, void* tape, size_t tape_bytes,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the tail of the training step on the device: no host synchronisation ------------------------
+ * Flat layout shared by the gradient / optimizer-state buffers: slot i (state_dict order) starts at
+ * dptnav_flat_offset(h, i) floats -- the sum of the previous slots' sizes, each rounded up to 64 floats (256 bytes) --
+ * and dptnav_flat_numel(h) floats hold all slots; the padding between slots must be zero.  The gradient pointers handed
+ * to dptnav_bind_grads may (and in speech_separation_amd do) point into one such buffer, so that data parallelism needs
+ * ONE all-reduce and clip + AdamW need no per-tensor launches. */
+int64_t dptnav_flat_offset(dptnav_handle h, int slot);
+int64_t dptnav_flat_numel(dptnav_handle h);
+size_t dptnav_tail_scratch_bytes(dptnav_handle h, int B);
+/* replaces: SiSNRWavLoss.forward + its autograd backward           src/loss/ss_losses.py:21-26 (BaseSSLoss: batch-level PIT),
+ *                                                                  :100-114 (SiSNRLoss), src/trainer/trainer.py:43,47
+ *   s1_pred, s2_pred, s1, s2 (B,T) fp32 -> loss_out[4] = {loss, chosen permutation (0: (p1,s1)+(p2,s2), 1: swapped),
+ *   loss of permutation 0, loss of permutation 1}; d_s1_pred, d_s2_pred (B,T) = grad_scale * d loss / d prediction -- the
+ *   inputs of dptnav_train_backward.  The permutation is resolved on the device (the reference converts a tensor to bool).
+ *   scratch: >= dptnav_tail_scratch_bytes(h, B) bytes, 8-byte aligned. */
+int dptnav_pit_sisnr_loss(dptnav_handle h, const float* s1_pred, const float* s2_pred, const float* s1, const float* s2,
+                          int B, int64_t T, float grad_scale, float* d_s1_pred, float* d_s2_pred, float* loss_out,
+                          void* scratch, size_t scratch_bytes, void* stream);
+/* replaces: clip_grad_norm_(model.parameters(), max_grad_norm)     src/trainer/base_trainer.py:383-391
+ *   flat_grad: n_flat floats in the flat layout; scaled in place by min(1, max_norm / (norm + 1e-6)); norm_out[0] = the
+ *   global L2 norm BEFORE clipping (what clip_grad_norm_ returns).  max_norm <= 0: norm only. */
+int dptnav_grad_clip(dptnav_handle h, float* flat_grad, int64_t n_flat, float max_norm, void* scratch, size_t scratch_bytes,
+                     float* norm_out, void* stream);
+/* replaces: torch.optim.AdamW.step()                               src/configs/dptn_wav_av.yaml:9-11, src/trainer/trainer.py:49
+ *   Updates IN PLACE the parameters bound with dptnav_bind_weights (those pointers must be writable); flat_grad,
+ *   exp_avg, exp_avg_sq: dptnav_flat_numel(h) floats each; step = 1 for the first update (bias correction). */
+int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
 /* Test helper: mask (nseq, heads, len, len) fp32 of ones/zeros = the keep-mask of path (block, path). */
 int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, float* mask, void* stream);
@@ -185,6 +215,8 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 change between a forward and its backward: the tape layout depends on it.
  *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
  *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
+ *   "inject_fail" (n > 0): fault injection for the error-path tests -- the n-th GEMM-engine launch from now on returns
+ *                 DPTNAV_ERR_INVALID (once); the forked entry points must still join their internal streams.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
  *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
 int dptnav_set_option(dptnav_handle h, const char* key, int value);

@@ -90,3 +90,24 @@ class StockDPTN:
             padn = T - y.shape[-1]
             preds.append(F.pad(y, (padn // 2, padn - padn // 2)).squeeze(1))
         return {"s1_pred": preds[0], "s2_pred": preds[1]}
+
+
+class SiSNRWavLossTorch(nn.Module):
+    """The reference's training loss restated with the same PyTorch operators -- ORACLE for dptnav_pit_sisnr_loss and for
+    torch.autograd comparisons of the training step (tests only).  Follows src/loss/ss_losses.py:100-114 (SiSNRLoss:
+    zero-mean, projection on the target, -20 log10(|a t|^2 / |p - a t|^2), batch mean, no eps) and :21-26 (BaseSSLoss:
+    batch-level PIT -- the smaller of the two permutations' batch means).  Pinned against values the reference's own
+    SiSNRWavLoss produced (tests/golden/*.npz `val.pit_loss`) by tests/test_oracle_golden.py."""
+
+    @staticmethod
+    def pair(pred, gt):
+        pred = pred - pred.mean(-1, keepdim=True)
+        gt = gt - gt.mean(-1, keepdim=True)
+        scale = (gt * pred).sum(-1, keepdim=True) / (gt * gt).sum(-1, keepdim=True)
+        st = scale * gt
+        return (-20 * torch.log10((st * st).sum(-1) / ((pred - st) ** 2).sum(-1))).mean()
+
+    def forward(self, s1_pred, s2_pred, s1, s2, **batch):
+        p1 = (self.pair(s1_pred, s1) + self.pair(s2_pred, s2)) / 2
+        p2 = (self.pair(s1_pred, s2) + self.pair(s2_pred, s1)) / 2
+        return {"loss": p2 if p2 < p1 else p1}

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdptnav.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DptnavConfig(C.Structure):
@@ -53,6 +53,12 @@ SYMBOLS = {
     "dptnav_train_workspace_bytes": (_sz, [_vp, _i, _i64, _i]),
     "dptnav_train_forward": (_i, [_vp, _fp, _fp, _fp, _i, _i64, _i, _fp, _fp, _vp, _sz, _vp, _sz, _vp]),
     "dptnav_train_backward": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _i64, _i, _vp, _sz, _vp, _sz, _vp]),
+    "dptnav_flat_offset": (_i64, [_vp, _i]),
+    "dptnav_flat_numel": (_i64, [_vp]),
+    "dptnav_tail_scratch_bytes": (_sz, [_vp, _i]),
+    "dptnav_pit_sisnr_loss": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i64, C.c_float, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "dptnav_grad_clip": (_i, [_vp, _fp, _i64, C.c_float, _vp, _sz, _fp, _vp]),
+    "dptnav_adamw_step": (_i, [_vp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp]),
     "dptnav_dropout_mask": (_i, [_vp, _i, _i, _i, _i, _fp, _vp]),
     "dptnav_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dptnav_profile_enable": (_i, [_vp, _i]),

@@ -10,6 +10,7 @@
 //     order as long as A and B agree.  This makes every fragment fetch a ds_read_b128 /
 //     global_load_dwordx4.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -154,10 +155,12 @@ DEV int64_t pre_tile_offset(int d, int st, int t, int nst, int len) {
 
 // Host helper: "done once per HIP device" flags for function attributes (hipFuncSetAttribute applies to the device
 // that is current; a process may drive several GPUs through several engines).  Up to 64 devices.
+// Atomic: two engines may be driven from two host threads (each handle is single-threaded, the statics are shared);
+// the guarded work (hipFuncSetAttribute, an occupancy query) is idempotent, so a lost race only repeats it.
 struct PerDeviceOnce {
-  uint64_t mask = 0;
-  bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask >> dev) & 1u); }
-  void set(int dev) { if (dev >= 0 && dev < 64) mask |= (uint64_t)1 << dev; }
+  std::atomic<uint64_t> mask{0};
+  bool done(int dev) const { return dev >= 0 && dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1u); }
+  void set(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or((uint64_t)1 << dev, std::memory_order_release); }
 };
 inline int current_hip_device() {
   int d = 0;

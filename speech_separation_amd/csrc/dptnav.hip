@@ -17,6 +17,7 @@
 #include "lstm.h"
 #include "lstm16.h"
 #include "sisnr.h"
+#include "train_tail.h"
 #include "backward.h"
 #include "backward_ends.h"
 
@@ -75,6 +76,7 @@ struct dptnav_ctx {
   bool opt_overlap = true;
   bool opt_lstm16 = true;
   int opt_lstm_diag = 0;
+  int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
   DropCfg drop_cfg(int block, int path, bool train, int half = 0) const {
@@ -383,11 +385,13 @@ template <int KIN, int NT, int WR, int WC, bool WT = false, class AL, class EP>
 int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float* W, int64_t ntiles, int colgroups,
                 const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr) {
   hipStream_t st = run.st;
+  if (c->opt_inject_fail > 0 && --c->opt_inject_fail == 0)   // fault injection for the error-path tests (option "inject_fail")
+    return c->fail(DPTNAV_ERR_INVALID, "%s: injected failure", what);
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
-  static int resident_dev[64] = {};  // per instantiation and device
-  int& resident = resident_dev[c->device_id & 63];
+  static std::atomic<int> resident_dev[64];  // per instantiation and device (zero-initialised; idempotent fill)
+  int resident = resident_dev[c->device_id & 63].load(std::memory_order_acquire);
   if (resident == 0) {
     if (int rc = set_lds(c, kern, lds, what)) return rc;
     int per_cu = 0;
@@ -396,6 +400,7 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
     // two workgroups per CU cover each other's barriers; a third only adds a weight-load prologue per launch
     // (out-projection GEMM: 0.157 ms with 512 workgroups, 0.160 with 768)
     resident = std::min(per_cu, 2) * c->num_cus;
+    resident_dev[c->device_id & 63].store(resident, std::memory_order_release);
   }
   int gx = resident / colgroups;
   if (gx < 1) gx = 1;
@@ -1060,6 +1065,21 @@ int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st
   return DPTNAV_OK;
 }
 
+// Join the caller's stream to BOTH internal streams (always, also after a failed enqueue: kernels already queued there
+// must be ordered before whatever the caller does next) and return the body's error, or the join's if the body was fine.
+int join_after(dptnav_ctx* c, hipStream_t st, bool forked, int rc_body) {
+  if (!forked) return rc_body;
+  const std::string body_err = c->err;
+  bool ok = true;
+  for (int s = 0; s < 2; ++s)
+    ok &= hipEventRecord(c->ev_join[s], c->streams[s]) == hipSuccess && hipStreamWaitEvent(st, c->ev_join[s], 0) == hipSuccess;
+  if (rc_body) {
+    c->err = body_err;
+    return rc_body;
+  }
+  return ok ? DPTNAV_OK : c->fail(DPTNAV_ERR_HIP, "join event");
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1284,6 +1304,10 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   Run run[MAX_SUB];
   const float *mixi[MAX_SUB], *e1i[MAX_SUB], *e2i[MAX_SUB];
   float *s1i[MAX_SUB], *s2i[MAX_SUB];
+  // Everything between the fork and the join runs inside `enqueue`: whatever it returns, the caller's stream is joined
+  // to the two internal streams afterwards, so work already enqueued there is ordered before anything the caller does
+  // next with the workspace / output tensors (it may free them when it sees the error).
+  auto enqueue = [&]() -> int {
   int64_t b0 = 0;
   for (int i = 0; i < nsub; ++i) {
     hipStream_t si = nsub > 1 ? h->streams[i & 1] : st;   // sub-batches alternate between the two streams
@@ -1327,11 +1351,10 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
                  : run_tail<64>(h, run[i], X0(i), E(i), Bs[i], T, s1i[i], s2i[i]);
     if (rc) return rc;
   }
-  if (nsub > 1)
-    for (int s = 0; s < 2; ++s)
-      if (hipEventRecord(h->ev_join[s], h->streams[s]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[s], 0) != hipSuccess)
-        return h->fail(DPTNAV_ERR_HIP, "join event");
   return DPTNAV_OK;
+  };
+  const int rc_body = enqueue();
+  return join_after(h, st, nsub > 1, rc_body);
 }
 
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* off, size_t* numel) {
@@ -1358,6 +1381,82 @@ int dptnav_sisnr_pairs(dptnav_handle h, const float* s1_pred, const float* s2_pr
   hipLaunchKernelGGL(sisnr_pairs_kernel, dim3(B, 6), dim3(256), 0, (hipStream_t)stream, s1_pred, s2_pred, s1, s2, mix, T,
                      out);
   LAUNCH_CHECK(h, "sisnr_pairs");
+  return DPTNAV_OK;
+}
+
+// ---- the training step's tail on the device (N1): loss forward + backward, clip, AdamW; no host synchronisation ----
+int64_t dptnav_flat_offset(dptnav_handle h, int slot) {
+  if (!h || slot < 0 || slot > (int)h->numel.size()) return -1;
+  int64_t o = 0;
+  for (int i = 0; i < slot; ++i) o += (int64_t)align64((size_t)h->numel[i]);
+  return o;
+}
+int64_t dptnav_flat_numel(dptnav_handle h) { return h ? dptnav_flat_offset(h, (int)h->numel.size()) : -1; }
+
+size_t dptnav_tail_scratch_bytes(dptnav_handle h, int B) {
+  if (!h || B < 1) return 0;
+  return ((size_t)B * 4 * PIT_STAT + CLIP_PARTS) * sizeof(double);
+}
+
+int dptnav_pit_sisnr_loss(dptnav_handle h, const float* s1_pred, const float* s2_pred, const float* s1, const float* s2, int B,
+                          int64_t T, float grad_scale, float* d_s1_pred, float* d_s2_pred, float* loss_out, void* scratch,
+                          size_t scratch_bytes, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!s1_pred || !s2_pred || !s1 || !s2 || !d_s1_pred || !d_s2_pred || !loss_out || B < 1 || T < 2)
+    return h->fail(DPTNAV_ERR_INVALID, "pit_sisnr_loss: bad argument");
+  if (!scratch || ((uintptr_t)scratch & 7) || scratch_bytes < dptnav_tail_scratch_bytes(h, B))
+    return h->fail(DPTNAV_ERR_WORKSPACE, "pit_sisnr_loss: scratch too small / misaligned (need %zu bytes)",
+                   dptnav_tail_scratch_bytes(h, B));
+  hipStream_t st = (hipStream_t)stream;
+  double* stats = (double*)scratch;
+  hipLaunchKernelGGL(pit_stats_kernel, dim3(B, 4), dim3(256), 0, st, s1_pred, s2_pred, s1, s2, T, stats);
+  hipLaunchKernelGGL(pit_grad_kernel, dim3((unsigned)((T + 1023) / 1024), B, 2), dim3(256), 0, st, s1_pred, s2_pred, s1, s2, B, T,
+                     stats, grad_scale, d_s1_pred, d_s2_pred, loss_out);
+  LAUNCH_CHECK(h, "pit_sisnr_loss");
+  return DPTNAV_OK;
+}
+
+int dptnav_grad_clip(dptnav_handle h, float* flat_grad, int64_t n_flat, float max_norm, void* scratch, size_t scratch_bytes,
+                     float* norm_out, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!flat_grad || !norm_out || n_flat < 4 || (n_flat & 3) || ((uintptr_t)flat_grad & 15))
+    return h->fail(DPTNAV_ERR_INVALID, "grad_clip: flat gradient must be 16-byte aligned with a multiple of 4 floats");
+  if (!scratch || ((uintptr_t)scratch & 7) || scratch_bytes < CLIP_PARTS * sizeof(double))
+    return h->fail(DPTNAV_ERR_WORKSPACE, "grad_clip: scratch too small / misaligned");
+  hipStream_t st = (hipStream_t)stream;
+  double* partials = (double*)scratch;
+  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(CLIP_PARTS), dim3(256), 0, st, flat_grad, n_flat / 4, partials);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(h->num_cus * 2), dim3(256), 0, st, flat_grad, n_flat / 4, partials, CLIP_PARTS, max_norm,
+                     norm_out);
+  LAUNCH_CHECK(h, "grad_clip");
+  return DPTNAV_OK;
+}
+
+int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!h) return DPTNAV_ERR_INVALID;
+  if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "adamw_step: weights not bound (the step updates the bound parameters in place)");
+  if (!flat_grad || !exp_avg || !exp_avg_sq || n_flat != dptnav_flat_numel(h) || step < 1)
+    return h->fail(DPTNAV_ERR_INVALID, "adamw_step: bad argument (flat buffers must hold %lld floats, step >= 1)",
+                   (long long)dptnav_flat_numel(h));
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+  const float decay = (float)(1.0 - (double)lr * weight_decay);
+  const int n = (int)h->names.size();
+  int64_t off = 0;
+  for (int lo = 0; lo < n; lo += ADAMW_MAX) {
+    AdamwArgs a{};
+    const int cnt = std::min(ADAMW_MAX, n - lo);
+    for (int e = 0; e < cnt; ++e) {
+      a.param[e] = const_cast<float*>(h->ptr[lo + e]);
+      a.off[e] = off;
+      a.n[e] = (int)h->numel[lo + e];
+      off += (int64_t)align64((size_t)h->numel[lo + e]);
+    }
+    hipLaunchKernelGGL(adamw_kernel, dim3(cnt, ADAMW_YBLOCKS), dim3(256), 0, (hipStream_t)stream, a, flat_grad, exp_avg, exp_avg_sq,
+                       lr, beta1, beta2, eps, decay, step_size, inv_sqrt_bc2);
+    LAUNCH_CHECK(h, "adamw_step");
+  }
   return DPTNAV_OK;
 }
 
@@ -1497,13 +1596,6 @@ static int train_fork(dptnav_handle h, const TrainSplit& sp, hipStream_t st, hip
   }
   return DPTNAV_OK;
 }
-static int train_join(dptnav_handle h, const TrainSplit& sp, hipStream_t st, const hipStream_t* si) {
-  if (sp.nhalf == 1) return DPTNAV_OK;
-  for (int i = 0; i < 2; ++i)
-    if (hipEventRecord(h->ev_join[i], si[i]) != hipSuccess || hipStreamWaitEvent(st, h->ev_join[i], 0) != hipSuccess)
-      return h->fail(DPTNAV_ERR_HIP, "join event");
-  return DPTNAV_OK;
-}
 
 int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,
                          float* s1, float* s2, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
@@ -1517,6 +1609,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
   if (!mix || !s1 || !s2 || (!h->cfg.audio_only && (!e1 || !e2 || Tv < 1))) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
   hipStream_t st = (hipStream_t)stream, si[2];
   if (int rc = train_fork(h, sp, st, si)) return rc;
+  auto enqueue = [&]() -> int {   // between fork and join: see join_after
   const int nb = h->cfg.num_blocks;
   const int64_t Cv = h->cfg.audio_only ? 0 : h->cfg.video_emb_size;
   Run run[2];
@@ -1555,7 +1648,10 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
                                s1 + b0[i] * T, s2 + b0[i] * T, tb[i] + mt.Z))
       return rc;
   }
-  return train_join(h, sp, st, si);
+  return DPTNAV_OK;
+  };
+  const int rc_body = enqueue();
+  return join_after(h, st, sp.nhalf == 2, rc_body);
 }
 
 // grads[i] += scratch[i] for up to GRAD_ADD_MAX parameters per launch (pointers travel as kernel arguments)
@@ -1585,6 +1681,7 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
   if (!mix || !d_s1 || !d_s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
   hipStream_t st = (hipStream_t)stream, si[2];
   if (int rc = train_fork(h, sp, st, si)) return rc;
+  auto enqueue = [&]() -> int {   // between fork and join: see join_after
   const int nb = h->cfg.num_blocks;
   const int64_t Cv = h->cfg.audio_only ? 0 : h->cfg.video_emb_size;
   const int64_t b0[2] = {0, sp.Bh[0]};
@@ -1644,7 +1741,9 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
                                         e2 ? e2 + b0[i] * Cv * Tv : nullptr, tb[i] + sp.mt[i].vid, dcur[i], sp.Bh[i], T,
                                         sp.pl[i].L, (int)sp.pl[i].S, Tv))
       return rc;
-  if (int rc = train_join(h, sp, st, si)) return rc;
+  return DPTNAV_OK;
+  };
+  if (int rc = join_after(h, st, sp.nhalf == 2, enqueue())) return rc;
   if (sp.nhalf == 2) {
     const int n = (int)h->names.size();
     for (int lo = 0; lo < n; lo += GRAD_ADD_MAX) {
@@ -1683,6 +1782,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
+  else if (k == "inject_fail") h->opt_inject_fail = value;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }

@@ -204,14 +204,8 @@ class DptnEngine:
         """Allocate the gradient buffers the library WRITES and bind them; returns {key: tensor}.  All of them are views
         of ONE flat tensor (`self._grads_flat`, every slot at a 256-byte aligned offset `self._grad_offsets[key]`), so
         that a step can be handed to autograd with one copy and to RCCL with one collective."""
-        offs, o = {}, 0
-        for key, shape in self.slots:
-            offs[key] = o
-            n = 1
-            for d in shape:
-                n *= int(d)
-            o += (n + 63) // 64 * 64
-        flat = torch.zeros(o, device=self.device)
+        offs = self.flat_offsets()
+        flat = torch.zeros(self.flat_numel(), device=self.device)
         grads, ptrs = {}, (C.c_void_p * len(self.slots))()
         for i, (key, shape) in enumerate(self.slots):
             n = 1
@@ -225,6 +219,58 @@ class DptnEngine:
             self._raise(rc, "dptnav_bind_grads")
         self._grads, self._grads_flat, self._grad_offsets = grads, flat, offs
         return grads
+
+    # ------------------------------------------------------------------ flat layout / training tail (N1)
+    def flat_offsets(self) -> Dict[str, int]:
+        """{state_dict key: offset in floats} of the flat gradient / optimizer-state layout (include/dptnav.h)."""
+        return {key: int(self.lib.dptnav_flat_offset(self._h, i)) for i, (key, _) in enumerate(self.slots)}
+
+    def flat_numel(self) -> int:
+        return int(self.lib.dptnav_flat_numel(self._h))
+
+    def _tail_scratch(self, B: int) -> torch.Tensor:
+        need = int(self.lib.dptnav_tail_scratch_bytes(self._h, max(B, 1)))
+        if getattr(self, "_tail_ws", None) is None or self._tail_ws.numel() < need:
+            self._tail_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._tail_ws
+
+    def pit_sisnr_loss(self, s1_pred, s2_pred, s1, s2, grad_scale: float = 1.0):
+        """-> (d loss / d s1_pred, d loss / d s2_pred, out[4] = loss, permutation, loss perm 0, loss perm 1); all on the
+        device, no synchronisation."""
+        B, T = s1_pred.shape
+        ts = [_check(t.detach(), n, (B, T), self.device) for t, n in ((s1_pred, "s1_pred"), (s2_pred, "s2_pred"), (s1, "s1"),
+                                                                     (s2, "s2"))]
+        d1, d2 = torch.empty_like(ts[0]), torch.empty_like(ts[1])
+        out = torch.empty(4, device=self.device)
+        ws = self._tail_scratch(B)
+        rc = self.lib.dptnav_pit_sisnr_loss(self._h, *[t.data_ptr() for t in ts], B, T, float(grad_scale), d1.data_ptr(),
+                                            d2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_pit_sisnr_loss")
+        return d1, d2, out
+
+    def grad_clip(self, flat_grad: torch.Tensor, max_norm: Optional[float]) -> torch.Tensor:
+        """Scales `flat_grad` (flat layout) in place like clip_grad_norm_; returns the pre-clip norm as a 0-dim device tensor."""
+        flat_grad = _check(flat_grad, "flat_grad", (self.flat_numel(),), self.device)
+        norm = torch.empty(1, device=self.device)
+        ws = self._tail_scratch(1)
+        rc = self.lib.dptnav_grad_clip(self._h, flat_grad.data_ptr(), flat_grad.numel(),
+                                       float(max_norm) if max_norm is not None else 0.0, ws.data_ptr(), ws.numel(),
+                                       norm.data_ptr(), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_grad_clip")
+        return norm[0]
+
+    def adamw_step(self, flat_grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step: int):
+        n = self.flat_numel()
+        for t, name in ((flat_grad, "flat_grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            _check(t, name, (n,), self.device)
+            if not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous")
+        rc = self.lib.dptnav_adamw_step(self._h, flat_grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, float(lr),
+                                        float(beta1), float(beta2), float(eps), float(weight_decay), int(step), self._stream())
+        if rc:
+            self._raise(rc, "dptnav_adamw_step")
 
     def train_path_forward(self, block: int, path: int, x: torch.Tensor):
         B, S, K, N = x.shape

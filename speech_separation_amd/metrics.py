@@ -1,4 +1,4 @@
-"""Loss value and SI-SNR(i) metrics computed on the GPU with ONE kernel launch and ONE device->host copy.
+"""PIT SI-SNR loss (forward + backward) and SI-SNR(i) metrics computed on the GPU.
 
 Mirrors (does not import) the reference interfaces that consume the model's outputs:
   * ``SiSNRWavLoss()(**batch) -> {"loss": tensor}``          src/loss/ss_losses.py:117-130 (+ BaseSSLoss :21-26)
@@ -7,10 +7,11 @@ Mirrors (does not import) the reference interfaces that consume the model's outp
 Both resolve the speaker permutation at BATCH level (compare the two batch means), exactly as the reference does
 (ss_losses.py:21-25, base_metric.py:57-60) -- this is not per-utterance PIT.
 
-The reference needs >= 6 ``.item()`` syncs per batch for this (base_metric.py:53-56, si_snri.py:25-26); here the
-per-item statistics come from ``dptnav_sisnr_pairs`` and the 12*B numbers are reduced on the host.
-Forward values only (evaluation / logging): the training loss with gradients belongs to the backward work that
-is not built yet.
+The reference needs >= 6 ``.item()`` syncs per batch for the metrics (base_metric.py:53-56, si_snri.py:25-26); here the
+per-item statistics come from ``dptnav_sisnr_pairs`` (one launch) and the 12*B numbers are reduced on the host with ONE
+device->host copy.  The LOSS never touches the host: ``dptnav_pit_sisnr_loss`` resolves the permutation on the device,
+returns the loss as a 0-dim device tensor and leaves d loss / d prediction ready for ``loss.backward()`` (two launches
+instead of ~40 PyTorch kernels and a tensor->bool conversion).
 """
 from __future__ import annotations
 
@@ -41,14 +42,30 @@ def pair_statistics(s1_pred, s2_pred, s1, s2, mix) -> torch.Tensor:
     return stats.double().mean(0).cpu()
 
 
-class SiSNRWavLoss:
-    """Forward value of the reference's PIT SI-SNR loss (batch-level permutation, -20 log10, no eps)."""
+class _PitSisnrFn(torch.autograd.Function):
+    """loss = BaseSSLoss(SiSNRLoss) (ss_losses.py:21-26,100-114); the forward launch pair already writes the gradient."""
 
-    def __call__(self, s1_pred, s2_pred, s1, s2, mix=None, **batch):
-        m = pair_statistics(s1_pred, s2_pred, s1, s2, s1_pred if mix is None else mix)[:, 1]
-        perm1 = (m[0] + m[3]) / 2
-        perm2 = (m[1] + m[2]) / 2
-        return {"loss": perm2 if perm2 < perm1 else perm1}
+    @staticmethod
+    def forward(ctx, s1_pred, s2_pred, s1, s2):
+        d1, d2, out = _engine(s1_pred.device).pit_sisnr_loss(s1_pred, s2_pred, s1, s2)
+        ctx.save_for_backward(d1, d2)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        d1, d2 = ctx.saved_tensors
+        return g * d1, g * d2, None, None
+
+
+class SiSNRWavLoss(torch.nn.Module):
+    """The reference's PIT SI-SNR loss: ``SiSNRWavLoss()(**batch) -> {"loss": 0-dim tensor}`` (ss_losses.py:117-130),
+    differentiable w.r.t. s1_pred / s2_pred, no host synchronisation.  ``self.last`` keeps the device tensor
+    [loss, permutation, loss perm 0, loss perm 1] of the latest call for logging."""
+
+    def forward(self, s1_pred, s2_pred, s1, s2, **batch):
+        loss, self.last = _PitSisnrFn.apply(s1_pred, s2_pred, s1, s2)
+        return {"loss": loss}
 
 
 class SISNRMetric:

@@ -19,6 +19,8 @@ model's compute and there is no CPU fallback -- a missing extension or a CPU ten
 from __future__ import annotations
 
 import math
+import os
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -79,12 +81,7 @@ class _SeparateFn(torch.autograd.Function):
         eng = module._get_engine(mix.device)
         if getattr(eng, "_grads", None) is None:
             eng.bind_grads()
-        # train-mode attention dropout (dptn.py:16-21): a fresh seed per step, the same one for this step's backward
-        ppm = int(round(module.cfg.dropout * 1e6)) if module.training else 0
-        module._drop_step = getattr(module, "_drop_step", 0) + 1
-        seed = (torch.initial_seed() * 2654435761 + module._drop_step * 40503) & 0x7FFFFFFF
-        eng.set_option("dropout_ppm", ppm)
-        eng.set_option("dropout_seed", seed)
+        ppm, seed = module._arm_dropout(eng)
         s1, s2, tape = eng.train_forward(mix, e1, e2)
         ctx.module, ctx.tape, ctx.inputs, ctx.drop = module, tape, (mix, e1, e2), (ppm, seed)
         return s1, s2
@@ -124,6 +121,7 @@ class _DPTNBase(nn.Module):
             p = nn.Parameter(torch.empty(*shape))
             node.register_parameter(parts[-1], p)
             _init_like_torch(key, p, cfg)
+            p._dptnav_owner = weakref.ref(self)      # lets optim.FusedAdamW / clip_grad_norm_ find the engine
         self._engine: Optional[DptnEngine] = None
 
     # -- engine management -------------------------------------------------------------------
@@ -146,15 +144,39 @@ class _DPTNBase(nn.Module):
             eng.bind(params)  # borrows the nn.Parameter storages (optimizer / load_state_dict stay in charge)
         return eng
 
+    def _arm_dropout(self, eng: DptnEngine):
+        """Train-mode attention dropout (dptn.py:16-21): a fresh seed per call, kept for this call's backward.  Data-parallel
+        ranks share torch's seed, so the rank is mixed in to keep their masks apart."""
+        ppm = int(round(self.cfg.dropout * 1e6)) if self.training else 0
+        self._drop_step = getattr(self, "_drop_step", 0) + 1
+        rank = int(os.environ.get("RANK", "0"))
+        seed = (torch.initial_seed() * 2654435761 + self._drop_step * 40503 + rank * 0x632BE5AB) & 0x7FFFFFFF
+        eng.set_option("dropout_ppm", ppm)
+        eng.set_option("dropout_seed", seed)
+        return ppm, seed
+
+    def _train_kernels_built(self) -> bool:
+        return self.cfg.arch == "dptn" and self.cfg.num_features == 128 and self.cfg.bidir
+
     def _run(self, mix, e1, e2):
+        cont = lambda t: None if t is None else t.contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.cfg.arch != "dptn" or self.cfg.num_features != 128 or not self.cfg.bidir:
+            if not self._train_kernels_built():
                 raise NotImplementedError("the training step (backward kernels) is built for the DPTN architecture with "
                                           "num_features=128, bidir=True (BASELINE config 4); use torch.no_grad() here")
-            s1, s2 = _SeparateFn.apply(self, mix.contiguous(), None if e1 is None else e1.contiguous(),
-                                       None if e2 is None else e2.contiguous(), *self.parameters())
+            s1, s2 = _SeparateFn.apply(self, mix.contiguous(), cont(e1), cont(e2), *self.parameters())
             return {"s1_pred": s1, "s2_pred": s2}
         eng = self._get_engine(mix.device)
+        # model.train() under torch.no_grad(): the reference still applies attention dropout (nn.MultiheadAttention looks at
+        # self.training only).  The dropout lives in the training kernels, so take that path and drop the tape; where it
+        # is not built, say so instead of silently returning the eval-mode result.  DPRNN blocks have no dropout.
+        if self.training and self.cfg.arch == "dptn" and self.cfg.dropout > 0:
+            if not self._train_kernels_built():
+                raise NotImplementedError("train-mode forward (attention dropout) is built for num_features=128, bidir=True "
+                                          "only: call model.eval() for inference")
+            self._arm_dropout(eng)
+            s1, s2, _tape = eng.train_forward(mix.contiguous(), cont(e1), cont(e2))
+            return {"s1_pred": s1, "s2_pred": s2}
         s1, s2 = eng.forward(mix, e1, e2)
         return {"s1_pred": s1, "s2_pred": s2}
 

@@ -121,10 +121,12 @@ def test_whole_model_backward_matches_autograd(dev, audio_only, lstm_tile):
 
 def test_training_steps_match_stock_pytorch(dev):
     """Three optimizer steps (PIT SI-SNR loss, clip 10, AdamW 1e-3 = src/configs/dptn_wav_av.yaml:9-11,25) through the
-    nn.Module drop-in vs the same steps on the stock-PyTorch CPU composition with torch.autograd."""
+    nn.Module drop-in with the device loss / clip / FusedAdamW vs the same steps on the stock-PyTorch CPU composition with
+    torch.autograd, the torch-operator loss (oracle, pinned to the reference's values), torch's clip and torch.optim.AdamW."""
+    from oracle.torch_stock import SiSNRWavLossTorch
     from speech_separation_amd import DPTNAVWavEncDec
     from speech_separation_amd.spec import synthetic_inputs
-    from speech_separation_amd.train import SiSNRWavLoss, train_step
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
     kw = dict(num_features=128, video_emb_size=512, hidden_video=128, kernel_size_enc=7, hidden_dim=128, num_blocks=1,
               chunk_size=150, step_size=75, dropout=0.0, num_heads=4, bidir=True)
     model = DPTNAVWavEncDec(**kw)
@@ -132,12 +134,12 @@ def test_training_steps_match_stock_pytorch(dev):
     sd = synthetic_state_dict(cfg, seed=5)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
     inp = synthetic_inputs(cfg, B=2, T=2000, Tv=50, seed=8)
     ours = []
     for _ in range(3):
         batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
-        ours.append(train_step(model, batch, SiSNRWavLoss(), opt, max_grad_norm=10.0))
+        ours.append({k: float(v) for k, v in train_step(model, batch, SiSNRWavLoss(), opt, max_grad_norm=10.0).items()})
     # autograd adopted the per-parameter views of the step's ONE flat gradient copy (no 228 copies, one collective)
     flat = model._flat_grad
     assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in model.parameters())
@@ -158,9 +160,15 @@ def test_training_steps_match_stock_pytorch(dev):
     stock = Stock()
     sopt = torch.optim.AdamW(stock.parameters(), lr=1e-3)
     theirs = []
-    for _ in range(3):
+    for _ in range(3):      # trainer.py:38-51 with stock operators
         batch = {k: torch.from_numpy(v) for k, v in inp.items()}
-        theirs.append(train_step(stock, batch, SiSNRWavLoss(), sopt, max_grad_norm=10.0))
+        sopt.zero_grad()
+        batch.update(stock(**batch))
+        loss = SiSNRWavLossTorch()(**batch)["loss"]
+        loss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(stock.parameters(), 10.0)
+        sopt.step()
+        theirs.append({"loss": float(loss), "grad_norm": float(norm)})
     for a, b in zip(ours, theirs):
         assert abs(a["loss"] - b["loss"]) < 2e-3 * max(1.0, abs(b["loss"])), (ours, theirs)
         assert abs(a["grad_norm"] - b["grad_norm"]) < 1e-3 * b["grad_norm"], (ours, theirs)

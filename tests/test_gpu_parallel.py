@@ -1,0 +1,101 @@
+"""Multi-rank code paths on ONE GPU (rehearsal: the ranks share cuda:0 and talk over gloo; on an 8-GPU node the same
+code runs one rank per GPU over RCCL).
+
+  * the real DPTNAVWavEncDec training step at world size 2: after train.allreduce_gradients the model's flat gradient
+    tensor is the mean of the two ranks' gradients, reduced IN PLACE by one collective (trainer.py:47 + the
+    data-parallel all-reduce this repo adds);
+  * `python bench.py --gpus 2` with no launcher on the command line starts its own ranks and prints one JSON line with
+    n_gpus = 2 (forward and training-step configurations).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from speech_separation_amd import DPTNAVWavEncDec
+    from speech_separation_amd.metrics import SiSNRWavLoss
+    from speech_separation_amd.parallel import DistEnv
+    from speech_separation_amd.spec import synthetic_inputs, synthetic_state_dict
+    from speech_separation_amd.train import allreduce_gradients
+    env = DistEnv.from_environ(expected_world=world, backend="gloo", device="cuda:0")
+    dev = env.device
+    model = DPTNAVWavEncDec(num_features=128, video_emb_size=512, hidden_video=128, kernel_size_enc=7, hidden_dim=128,
+                            num_blocks=1, chunk_size=150, step_size=75, num_heads=4, dropout=0.0, bidir=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+    model = model.to(dev).train()
+    inp = synthetic_inputs(model.cfg, B=3, T=2500, Tv=50, seed=40 + rank)          # each rank: its own shard
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    batch.update(model(**batch))
+    SiSNRWavLoss()(**batch)["loss"].backward()
+    flat = model._flat_grad
+    local = flat.detach().clone()
+    how = allreduce_gradients(model, env)
+    torch.cuda.synchronize(dev)
+    # every rank's local gradient, gathered on the host, to state the expected mean independently of the collective
+    gathered = [torch.empty_like(local, device="cpu") for _ in range(world)]
+    dist.all_gather(gathered, local.cpu())
+    want = torch.stack(gathered).double().mean(0)
+    same_storage = all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in model.parameters())
+    err = float((flat.cpu().double() - want).abs().max() / want.abs().max())
+    differ = float((gathered[0] - gathered[1]).abs().max())
+    q.put((rank, how, same_storage, err, differ, float(want.abs().max())))
+    env.close()
+
+
+def test_world2_training_step_allreduces_the_flat_gradient_in_place():
+    assert torch.cuda.is_available()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, how, same_storage, err, differ, scale in res:
+        assert how == "flat-in-place", how              # the model's own _flat_grad branch, one collective
+        assert same_storage                             # p.grad are views of the reduced tensor: the optimizer sees the mean
+        assert scale > 0 and differ > 1e-6 * scale      # the ranks really had different gradients
+        assert err < 1e-6, (rank, err)                  # mean of two fp32 numbers: exact up to one rounding
+
+
+def _run_bench(extra):
+    env = dict(os.environ, BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["dptn_av", "dptn_av_train"])
+def test_bench_launches_its_own_ranks(config):
+    line = _run_bench(["--config", config])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    # whole-job throughput counts both ranks' mixtures
+    assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]

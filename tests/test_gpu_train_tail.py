@@ -1,0 +1,177 @@
+"""The tail of the training step on the device, through the C ABI:
+  * dptnav_pit_sisnr_loss  vs torch.autograd (fp64) on oracle/torch_stock.SiSNRWavLossTorch, which is itself pinned to the
+    values the reference's SiSNRWavLoss produced (tests/test_oracle_golden.py), and vs the golden `val.pit_loss`;
+  * dptnav_grad_clip       vs torch.nn.utils.clip_grad_norm_ (base_trainer.py:383-391) on the same gradients;
+  * dptnav_adamw_step      vs torch.optim.AdamW (dptn_wav_av.yaml:9-11) on the same gradients, incl. state_dict exchange;
+  * the whole step enqueues without a single host synchronisation (torch's sync debug mode set to "error").
+Tolerances: the kernels compute in fp32 (statistics in fp64); stated per check.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dptn_oracle as O
+from oracle.torch_stock import SiSNRWavLossTorch
+from speech_separation_amd.spec import synthetic_inputs, synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def small_model(dev, dropout=0.0, seed=5, blocks=1):
+    from speech_separation_amd import DPTNAVWavEncDec
+    model = DPTNAVWavEncDec(num_features=128, video_emb_size=512, hidden_video=128, kernel_size_enc=7, hidden_dim=128,
+                            num_blocks=blocks, chunk_size=150, step_size=75, dropout=dropout, num_heads=4, bidir=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=seed).items()})
+    return model.to(dev).train()
+
+
+@pytest.mark.parametrize("B,T,swap", [(5, 3001, False), (5, 3001, True), (1, 5, False), (16, 32000, True)])
+def test_pit_loss_and_its_gradient_match_autograd(dev, B, T, swap):
+    from speech_separation_amd.metrics import SiSNRWavLoss
+    rng = np.random.default_rng(B * 7 + T)
+    s1 = (0.1 * rng.standard_normal((B, T)) + 0.02).astype(np.float32)        # non-zero means: the centring matters
+    s2 = (0.1 * rng.standard_normal((B, T)) - 0.01).astype(np.float32)
+    p1 = (s1 + 0.05 * rng.standard_normal((B, T))).astype(np.float32)
+    p2 = (s2 + 0.2 * rng.standard_normal((B, T)) + 0.03).astype(np.float32)
+    if swap:                                                                   # the other permutation wins
+        p1, p2 = p2, p1
+    ref_in = {k: torch.from_numpy(v).double() for k, v in dict(s1_pred=p1, s2_pred=p2, s1=s1, s2=s2).items()}
+    ref_in["s1_pred"].requires_grad_(True)
+    ref_in["s2_pred"].requires_grad_(True)
+    want = SiSNRWavLossTorch()(**ref_in)["loss"]
+    (3.0 * want).backward()                                                    # upstream gradient != 1
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(s1_pred=p1, s2_pred=p2, s1=s1, s2=s2).items()}
+    t["s1_pred"].requires_grad_(True)
+    t["s2_pred"].requires_grad_(True)
+    crit = SiSNRWavLoss()
+    got = crit(**t, mix=None)["loss"]
+    assert got.dim() == 0 and got.device.type == "cuda"
+    (3.0 * got).backward()
+    assert abs(float(got) - float(want)) < 1e-4 * max(1.0, abs(float(want)))
+    last = crit.last.cpu()
+    assert int(last[1]) == int(swap) and abs(float(last[0]) - float(min(last[2], last[3]))) == 0.0
+    for k in ("s1_pred", "s2_pred"):
+        assert O.agreement_db(t[k].grad.cpu().numpy(), ref_in[k].grad.numpy()) > 100, k      # fp32 kernel vs fp64 autograd
+
+
+def test_device_loss_equals_the_reference_value(golden, dev):
+    """The value the reference's own SiSNRWavLoss computed on the reference's outputs (tests/golden mid_av)."""
+    from speech_separation_amd.metrics import SiSNRWavLoss
+    cfg, z = golden("mid_av")
+    B, T, Tv = (int(v) for v in z["shape"])
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=123)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    batch["s1_pred"] = torch.from_numpy(z["tap.s1_pred"]).to(dev)
+    batch["s2_pred"] = torch.from_numpy(z["tap.s2_pred"]).to(dev)
+    assert abs(float(SiSNRWavLoss()(**batch)["loss"]) - float(z["val.pit_loss"])) < 1e-3
+
+
+def _one_backward(model, dev, seed=8):
+    from speech_separation_amd.metrics import SiSNRWavLoss
+    inp = synthetic_inputs(model.cfg, B=2, T=2000, Tv=50, seed=seed)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    batch.update(model(**batch))
+    SiSNRWavLoss()(**batch)["loss"].backward()
+
+
+@pytest.mark.parametrize("max_norm_factor", [0.3, 5.0])       # clipping active / inactive
+def test_clip_and_adamw_match_torch_on_the_same_gradients(dev, max_norm_factor):
+    from speech_separation_amd.optim import FusedAdamW, clip_grad_norm_
+    model = small_model(dev)
+    _one_backward(model, dev)
+    names = [k for k, _ in model.named_parameters()]
+    g0 = [p.grad.detach().clone() for p in model.parameters()]
+    # stock side: independent copies of parameters and gradients
+    stock = [torch.nn.Parameter(p.detach().clone()) for p in model.parameters()]
+    sopt = torch.optim.AdamW(stock, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    fopt = FusedAdamW(model.parameters(), lr=1e-3)
+    total = float(torch.norm(torch.stack([g.norm() for g in g0])))
+    max_norm = max_norm_factor * total
+    before = [p.detach().clone() for p in model.parameters()]
+    for step in range(4):
+        scale = 1.0 + 0.5 * step                         # a different gradient every step (bias correction, moments)
+        for p, sp, g in zip(model.parameters(), stock, g0):
+            p.grad.copy_(g * scale)
+            sp.grad = g * scale
+        want_norm = torch.nn.utils.clip_grad_norm_(stock, max_norm)
+        got_norm = clip_grad_norm_(model.parameters(), max_norm)
+        assert got_norm.dim() == 0 and abs(float(got_norm) - float(want_norm)) < 1e-5 * float(want_norm)
+        for k, p, sp in zip(names, model.parameters(), stock):
+            assert torch.allclose(p.grad, sp.grad, rtol=1e-5, atol=1e-12), k          # clipped in place, like torch's
+        if step == 2:        # LR schedulers write the group's lr (OneCycleLR, dptn_wav_av.yaml:12-18)
+            fopt.param_groups[0]["lr"] = sopt.param_groups[0]["lr"] = 3e-4
+        sopt.step()
+        fopt.step()
+    worst = 1e9
+    for k, p, sp, b in zip(names, model.parameters(), stock, before):
+        upd_want, upd_got = (sp.detach() - b).double(), (p.detach() - b).double()
+        assert float(upd_want.abs().max()) > 0, k
+        worst = min(worst, O.agreement_db(upd_got.cpu().numpy(), upd_want.cpu().numpy()))
+    assert worst > 80, worst                              # the UPDATES agree to >= 80 dB (fp32 rounding of the same formula)
+    for p, sp in zip(model.parameters(), stock):
+        st, sst = fopt.state[p], sopt.state[sp]
+        assert torch.allclose(st["exp_avg"], sst["exp_avg"], rtol=1e-5, atol=1e-12)
+        assert torch.allclose(st["exp_avg_sq"], sst["exp_avg_sq"], rtol=1e-5, atol=1e-20)
+    # the forward sees the updated parameters without re-binding (pointers unchanged)
+    with torch.no_grad():
+        out = model.eval()(**{k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(model.cfg, B=1, T=2000, Tv=50, seed=1).items()})
+    assert torch.isfinite(out["s1_pred"]).all()
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_compatible(dev):
+    """base_trainer.py:476-478 saves optimizer.state_dict(), :528-535 loads it: both directions between the stock and the
+    fused optimizer, then one more identical step."""
+    from speech_separation_amd.optim import FusedAdamW
+    model = small_model(dev)
+    _one_backward(model, dev)
+    twin = small_model(dev)
+    twin.load_state_dict(model.state_dict())
+    fopt = FusedAdamW(model.parameters(), lr=1e-3)
+    sopt = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    for p, q in zip(model.parameters(), twin.parameters()):
+        q.grad = p.grad.detach().clone()
+    fopt.step()
+    sopt.step()
+    sd_f, sd_s = fopt.state_dict(), sopt.state_dict()
+    assert sd_f["state"].keys() == sd_s["state"].keys() and set(sd_f["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd_f["state"][0]["step"]) == 1.0
+    # cross-load and step again with the same gradients
+    f2 = FusedAdamW(model.parameters(), lr=1e-3)
+    f2.load_state_dict(sd_s)
+    s2 = torch.optim.AdamW(twin.parameters(), lr=1e-3)
+    s2.load_state_dict(sd_f)
+    f2.step()
+    s2.step()
+    for (k, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), k
+    assert f2._step == 2
+
+
+def test_training_step_enqueues_without_host_synchronisation(dev):
+    """zero_grad -> forward -> loss -> backward -> clip -> AdamW: no device->host synchronisation at all (the reference
+    step has >= 6 .item() calls plus a tensor->bool conversion in the loss).  torch's sync debug mode turns any
+    synchronising torch call into an error; libdptnav itself never synchronises (include/dptnav.h)."""
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
+    model = small_model(dev, dropout=0.1)
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=100, pct_start=0.1, anneal_strategy="cos")
+    crit = SiSNRWavLoss()
+    inp = synthetic_inputs(model.cfg, B=2, T=2000, Tv=50, seed=8)
+    batch0 = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    first = train_step(model, dict(batch0), crit, opt, 10.0, lr_scheduler=sched)            # allocations happen here
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        stats = [train_step(model, dict(batch0), crit, opt, 10.0, lr_scheduler=sched) for _ in range(3)]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    losses = [float(first["loss"])] + [float(s["loss"]) for s in stats]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(s["grad_norm"].device.type == "cuda" and float(s["grad_norm"]) > 0 for s in stats)

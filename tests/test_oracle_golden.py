@@ -49,6 +49,23 @@ def test_loss_matches_reference(golden, name):
     assert abs(got - float(z["val.pit_loss"])) < 1e-3
 
 
+@pytest.mark.parametrize("name", ["tiny_av", "tiny_audio", "tiny_dprnn"])
+def test_torch_loss_restatement_matches_reference(golden, name):
+    """oracle/torch_stock.SiSNRWavLossTorch (the autograd-able oracle of the device loss kernel) reproduces the values the
+    reference's own SiSNRWavLoss / SiSNRLoss gave on the reference's outputs."""
+    import torch
+    from oracle.torch_stock import SiSNRWavLossTorch
+    cfg, z = golden(name)
+    w, inp, ref = _split(z)
+    t = {k: torch.from_numpy(v) for k, v in {**inp, "s1_pred": ref["s1_pred"], "s2_pred": ref["s2_pred"]}.items()}
+    crit = SiSNRWavLossTorch()
+    assert abs(float(crit(**t)["loss"]) - float(z["val.pit_loss"])) < 1e-4 * max(1.0, abs(float(z["val.pit_loss"])))
+    for a in ("s1", "s2"):
+        for b in ("s1", "s2"):
+            assert abs(float(crit.pair(t[f"{a}_pred"], t[b])) - float(z[f"val.sisnr_loss_{a}_{b}"])) < 1e-4 * max(
+                1.0, abs(float(z[f"val.sisnr_loss_{a}_{b}"])))
+
+
 def test_metric_consistent_with_reference_loss(golden):
     """torchmetrics is unavailable (parity unpinned): SI-SNR dB must equal -loss/2 of the
     reference's own SiSNRLoss on the same pair (ss_losses.py:100-114)."""
