@@ -1454,7 +1454,7 @@ int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, f
       off += (int64_t)align64((size_t)h->numel[lo + e]);
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(cnt, ADAMW_YBLOCKS), dim3(256), 0, (hipStream_t)stream, a, flat_grad, exp_avg, exp_avg_sq,
-                       lr, beta1, beta2, eps, decay, step_size, inv_sqrt_bc2);
+                       beta1, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, decay, step_size, inv_sqrt_bc2);
     LAUNCH_CHECK(h, "adamw_step");
   }
   return DPTNAV_OK;

@@ -132,16 +132,18 @@ struct AdamwArgs {
   int n[ADAMW_MAX];
 };
 __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a, const float* __restrict__ grad, float* __restrict__ m,
-                                                     float* __restrict__ v, float lr, float beta1, float beta2, float eps,
-                                                     float decay /* 1 - lr * weight_decay */, float step_size /* lr / bc1 */,
-                                                     float inv_sqrt_bc2) {
+                                                     float* __restrict__ v, float beta1, float one_minus_beta1, float beta2,
+                                                     float one_minus_beta2 /* both 1 - beta in double on the host, as torch */,
+                                                     float eps, float decay /* 1 - lr * weight_decay */,
+                                                     float step_size /* lr / bc1 */, float inv_sqrt_bc2) {
   const int e = blockIdx.x;
   float* p = a.param[e];
   const int64_t o = a.off[e];
   for (int i = blockIdx.y * 256 + threadIdx.x; i < a.n[e]; i += ADAMW_YBLOCKS * 256) {
     const float g = grad[o + i];
-    const float mi = beta1 * m[o + i] + (1.0f - beta1) * g;          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = beta2 * v[o + i] + (1.0f - beta2) * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float m0 = m[o + i];
+    const float mi = m0 + one_minus_beta1 * (g - m0);                // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = beta2 * v[o + i] + one_minus_beta2 * (g * g);   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     m[o + i] = mi;
     v[o + i] = vi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;              // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)

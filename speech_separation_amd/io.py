@@ -53,24 +53,66 @@ def collate(items: Sequence[Mapping[str, object]]) -> Dict[str, object]:
     return batch
 
 
+def load_audio(path: str, target_sr: Optional[int] = None) -> torch.Tensor:
+    """(1, T) float32 in [-1, 1): first channel of a PCM WAV file, as BaseDataset.load_audio returns it
+    (base_dataset.py:137-145; torchaudio.load normalises integer PCM by 2^(bits-1)).  Resampling is not built: a file
+    whose rate differs from `target_sr` raises instead of being passed through."""
+    import wave
+    with wave.open(path, "rb") as w:
+        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if target_sr is not None and sr != target_sr:
+        raise ValueError(f"{path}: sample rate {sr} != {target_sr} (resampling is outside this path)")
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported PCM sample width {width}")
+    return torch.from_numpy(np.ascontiguousarray(x.reshape(-1, nch)[:, 0])).unsqueeze(0)
+
+
+def load_item(entry: Mapping[str, Optional[str]], target_sr: Optional[int] = None) -> Dict[str, object]:
+    """One dataset element from its index entry, the parts of BaseDataset.__getitem__ (base_dataset.py:56-135) this path
+    consumes: mix / s1 / s2 waveforms, the two lip embeddings, audio_path.  Spectrogram keys are not produced (the
+    separator ignores them, dptn_wav.py:171; they need torchaudio)."""
+    g = lambda k: entry.get(k)
+    item: Dict[str, object] = {"mix": load_audio(entry["mix_wav_path"], target_sr), "s1": None, "s2": None, "s1_video": None,
+                               "s2_video": None, "s1_embedding": None, "s2_embedding": None,
+                               "audio_path": entry["mix_wav_path"]}
+    if g("s1_wav_path") is not None:
+        item["s1"], item["s2"] = load_audio(entry["s1_wav_path"], target_sr), load_audio(entry["s2_wav_path"], target_sr)
+    if g("s1_embedding_path") is not None:
+        item["s1_embedding"], item["s2_embedding"] = load_object(entry["s1_embedding_path"]), load_object(entry["s2_embedding_path"])
+    return item
+
+
 class PinnedBatcher:
     """collate() into reusable pinned buffers + non-blocking H2D on a side stream.
 
     ``to_device(items)`` returns the batch dict with device tensors; the copies are ordered before later work on the
-    CURRENT stream by an event, so the caller can use the tensors as usual."""
+    CURRENT stream by an event, so the caller can use the tensors as usual.  Stream-ordering rules it keeps:
+      * the device tensors are allocated on the side stream and handed to the caller's stream with ``record_stream``, so
+        the caching allocator does not give their memory to the next batch's copy while a forward still reads them;
+      * the pinned staging buffers are a ring of ``depth`` sets, each guarded by an event recorded after its H2D copies:
+        a set is rewritten only after the copies that last read it have finished."""
 
-    def __init__(self, device, device_tensors: Sequence[str] = ("mix", "s1", "s2", "s1_embedding", "s2_embedding")):
+    def __init__(self, device, device_tensors: Sequence[str] = ("mix", "s1", "s2", "s1_embedding", "s2_embedding"),
+                 depth: int = 2):
         self.device = torch.device(device)
         self.device_tensors = list(device_tensors)
-        self._pinned: Dict[str, torch.Tensor] = {}
-        self._stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        cuda = self.device.type == "cuda"
+        self._sets: List[Dict[str, torch.Tensor]] = [dict() for _ in range(max(1, depth) if cuda else 1)]
+        self._events: List[Optional["torch.cuda.Event"]] = [None] * len(self._sets)
+        self._turn = 0
+        self._stream = torch.cuda.Stream(self.device) if cuda else None
 
-    def _stage(self, key: str, vals: List[torch.Tensor]) -> torch.Tensor:
+    def _stage(self, pinned: Dict[str, torch.Tensor], key: str, vals: List[torch.Tensor]) -> torch.Tensor:
         shape = (sum(v.shape[0] for v in vals),) + tuple(vals[0].shape[1:])
-        buf = self._pinned.get(key)
+        buf = pinned.get(key)
         if buf is None or tuple(buf.shape) != shape or buf.dtype != vals[0].dtype:
             buf = torch.empty(shape, dtype=vals[0].dtype, pin_memory=self.device.type == "cuda")
-            self._pinned[key] = buf
+            pinned[key] = buf
         o = 0
         for v in vals:                       # the concatenation itself: written straight into pinned memory
             buf[o:o + v.shape[0]].copy_(v)
@@ -80,6 +122,10 @@ class PinnedBatcher:
     def to_device(self, items: Sequence[Mapping[str, object]]) -> Dict[str, object]:
         batch: Dict[str, object] = {}
         staged = {}
+        i = self._turn
+        self._turn = (i + 1) % len(self._sets)
+        if self._events[i] is not None:
+            self._events[i].synchronize()    # the H2D copies that last read this pinned set are done
         for key in TENSOR_KEYS + LIST_KEYS:
             if key not in items[0]:
                 continue
@@ -88,16 +134,21 @@ class PinnedBatcher:
             elif key in LIST_KEYS:
                 batch[key] = [it[key] for it in items]
             elif key in self.device_tensors:
-                staged[key] = self._stage(key, [it[key] for it in items])
+                staged[key] = self._stage(self._sets[i], key, [it[key] for it in items])
             else:
                 batch[key] = torch.cat([it[key] for it in items], dim=0)
         if self._stream is None:
             batch.update({k: v.clone() for k, v in staged.items()})
             return batch
+        cur = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._stream):
             for k, v in staged.items():
                 batch[k] = v.to(self.device, non_blocking=True)
-        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+                batch[k].record_stream(cur)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        self._events[i] = ev
+        cur.wait_event(ev)
         return batch
 
 
@@ -114,3 +165,69 @@ def save_predictions(batch: Mapping[str, object], out_dir: str) -> List[str]:
         torch.save({k: v[i].clone() for k, v in host.items()}, p)
         paths.append(p)
     return paths
+
+
+class PredictionWriter:
+    """Asynchronous form of save_predictions for a running evaluation: ``submit(batch, out_dir)`` starts the
+    device->host copies on a side stream into pinned buffers and returns at once; a worker thread waits for them and
+    writes the ``<stem>.pth`` files (same layout).  ``close()`` drains the queue and returns the paths written."""
+
+    def __init__(self, device, depth: int = 3):
+        import queue
+        import threading
+        self.device = torch.device(device)
+        self._stream = torch.cuda.Stream(self.device)
+        self._q: "queue.Queue" = queue.Queue(maxsize=depth)
+        self._paths: List[str] = []
+        self._error: Optional[BaseException] = None
+        self._free: "queue.Queue" = queue.Queue()
+        for _ in range(depth + 1):
+            self._free.put({})
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            ev, host, names, out_dir, pinned = job
+            try:
+                ev.synchronize()
+                for i, ap in enumerate(names):
+                    p = os.path.join(out_dir, f"{Path(ap).stem}.pth")
+                    torch.save({k: v[i].clone() for k, v in host.items()}, p)
+                    self._paths.append(p)
+            except BaseException as e:      # surfaced by close()
+                self._error = e
+            finally:
+                self._free.put(pinned)
+
+    def submit(self, batch: Mapping[str, object], out_dir: str) -> None:
+        os.makedirs(out_dir, exist_ok=True)
+        src = {"s1_pred": batch["s1_pred"], "s2_pred": batch["s2_pred"]}
+        if batch.get("s1") is not None:
+            src["s1_true"], src["s2_true"] = batch["s1"], batch["s2"]
+        pinned = self._free.get()            # a pinned set no copy is writing and no file write is reading
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)        # the predictions are produced on the caller's stream
+        host = {}
+        with torch.cuda.stream(self._stream):
+            for k, v in src.items():
+                buf = pinned.get(k)
+                if buf is None or buf.shape != v.shape:
+                    buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    pinned[k] = buf
+                buf.copy_(v.detach(), non_blocking=True)
+                v.record_stream(self._stream)
+                host[k] = buf
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        self._q.put((ev, host, list(batch["audio_path"]), out_dir, pinned))
+
+    def close(self) -> List[str]:
+        self._q.put(None)
+        self._thread.join()
+        if self._error is not None:
+            raise self._error
+        return self._paths

@@ -51,3 +51,24 @@ def test_prediction_files_have_the_reference_layout(tmp_path):
     b["s1"] = b["s2"] = None                                       # no ground truth: only the predictions are written
     d = torch.load(save_predictions(b, str(tmp_path / "saved" / "test"))[0])
     assert set(d) == {"s1_pred", "s2_pred"}
+
+
+def test_wav_and_item_loading(tmp_path):
+    """load_audio == what torchaudio.load returns for PCM16 (first channel, / 32768, shape (1, T)); load_item builds the
+    element BaseDataset.__getitem__ builds (base_dataset.py:56-135) for the keys this path consumes."""
+    import pytest
+    from dataset_fixture import make_dataset
+    from speech_separation_amd.io import load_audio, load_item
+    entries, truth = make_dataset(str(tmp_path), n=2, T=801, Tv=7, emb=16)
+    a = load_audio(entries[1]["mix_wav_path"], target_sr=8000)
+    assert a.shape == (1, 801) and a.dtype == torch.float32 and np.array_equal(a[0].numpy(), truth[1]["mix"])
+    with pytest.raises(ValueError, match="sample rate"):
+        load_audio(entries[1]["mix_wav_path"], target_sr=16000)
+    it = load_item(entries[0], target_sr=8000)
+    assert it["audio_path"] == entries[0]["mix_wav_path"] and it["s1_video"] is None
+    assert it["s1_embedding"].shape == (1, 16, 7) and np.array_equal(it["s2_embedding"][0].numpy(), truth[0]["s2_embedding"])
+    assert np.array_equal(it["s2"][0].numpy(), truth[0]["s2"])
+    no_gt = load_item({"mix_wav_path": entries[0]["mix_wav_path"], "s1_wav_path": None, "s1_embedding_path": None})
+    assert no_gt["s1"] is None and no_gt["s1_embedding"] is None
+    b = collate([load_item(e) for e in entries])
+    assert b["mix"].shape == (2, 801) and b["s1_video"] is None
