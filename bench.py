@@ -62,14 +62,18 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def measured_traffic(tokens_per_launch: float):
-    """HBM bytes per LSTM launch from the committed PMC run (profiles/r01_lstm_hbm_traffic.json), rescaled to the
-    tokens one launch of THIS run covers; None if the file is absent.  bench.py cannot read PMC counters itself."""
-    path = os.path.join(ROOT, "profiles", "r01_lstm_hbm_traffic.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+def pmc_table(config: str):
+    """The committed per-kernel HBM-traffic table (tools/pmc_table.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes over `bench.py --pmc-run`, gfx950 corrections applied; its header names the commit and the command it was taken
+    at).  bench.py cannot read PMC counters itself, so `traffic` figures are FROM THIS FILE, for the configuration it was
+    measured on only (anything else reports null)."""
     try:
-        d = json.load(open(path))
-        return round(d["hbm_bytes_per_launch"] * tokens_per_launch / 169200.0)
-    except (OSError, KeyError, ValueError):
+        d = json.load(open(PMC_TABLE))
+        return d if d.get("config") == config else None
+    except (OSError, ValueError):
         return None
 
 
@@ -119,7 +123,8 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
             "configs0_convtasnet_cpu": {"value": round(conv_rate, 3), "unit": "mixtures/sec", "batch": 4,
                                         "note": "oracle/convtasnet_stock.py = src/model/convtasnet.py with stock PyTorch ops"},
             "sample": "oracle/torch_stock.py (stock PyTorch CPU ops, fp32, eval/no_grad), T=32000, 1 warm-up + "
-                      + "; ".join(parts) + "; max over B reported"}
+                      + "; ".join(parts) + "; max over B reported; B=16 not sampled (28.6 s per forward on 8 cores, and CPU throughput "
+                      "falls with B: BASELINE.md section 2)"}
 
 
 def self_launch(n: int) -> int:
@@ -138,6 +143,35 @@ def self_launch(n: int) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+def train_step_leg(cfg, dev, T, B=16, warmup=2, steps=5):
+    """BASELINE configs[3] next to the headline (N=1): a few optimizer steps of the same model at batch 16 -- forward with
+    tape, device PIT SI-SNR loss, HIP backward, device clip + AdamW, attention dropout 0.1 -- so that the driver-run line
+    carries a training-step figure too (`--config dptn_av_train` is the full-length measurement)."""
+    from speech_separation_amd import DPTNAVWavEncDec
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
+    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
+    model = DPTNAVWavEncDec(**kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+    model = model.to(dev).train()
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    batch0 = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123).items()}
+    crit = SiSNRWavLoss()
+    for _ in range(warmup):
+        train_step(model, dict(batch0), crit, opt, 10.0)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats = train_step(model, dict(batch0), crit, opt, 10.0)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    flops = 3.0 * model._engine.flops_per_mixture(T) * B
+    return {"workload": f"configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), batch={B}, T={T}, dropout 0.1",
+            "value": round(B / dt, 3), "unit": "mixtures/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+            "frac": round(flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "note": "frac = 3 x forward FLOPs (612 GFLOP per mixture) / time / fp32-MFMA peak; no host synchronisation in the step",
+            "last_loss": round(float(stats["loss"]), 4)}
 
 
 def bench_train(args, env, cfg, B, T, workload):
@@ -206,6 +240,10 @@ def main():
                     help="dptn_av (default) is the configuration BASELINE.json's metric is quoted on")
     ap.add_argument("--batch", type=int, default=0, help="mixtures per GPU per step (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the short configs[3] training-step measurement "
+                    "that the default N=1 headline run appends as `train_step`")
+    ap.add_argument("--pmc-run", action="store_true", help="warm-up + timed steps only (no per-kernel event pass, no isolated "
+                    "pass, no CPU leg): the command rocprofv3 --pmc / --kernel-trace passes are taken over")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -220,8 +258,10 @@ def main():
     torch.cuda.set_device(dev)
     cfg, B_default, T, workload = CONFIGS[args.config]
     B, Tv = args.batch or B_default, 50
-    if args.config != "dptn_av":
+    if args.config != "dptn_av" or args.pmc_run:
         args.no_cpu_baseline = True     # the CPU leg is only defined for the headline configuration
+    if args.config != "dptn_av" or args.pmc_run or env.world > 1:
+        args.no_train_step = True
     if args.config.endswith("_train"):
         return bench_train(args, env, cfg, B, T, workload)
 
@@ -247,6 +287,12 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    if args.pmc_run:
+        if env.rank == 0:
+            print(json.dumps({"pmc_run": True, "config": args.config, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(1e3 * elapsed / args.steps, 4)}), flush=True)
+        env.close()
+        return 0
 
     # ---- per-kernel device time: HIP events on the launch stream, same workload, separate pass ----------
     eng.profile(True)
@@ -304,6 +350,20 @@ def main():
         if iso is not None:
             iso["kernel"] = "lstm_recurrence_kernel"
         value = env.world * B * args.steps / elapsed
+        # HBM traffic: from the committed PMC table (same configuration, batch and kernel only), never extrapolated
+        tab = pmc_table(args.config)
+        traffic, traffic_unit, whole = None, "no PMC table for this configuration / kernel (profiles/r02_pmc_traffic.json)", None
+        if tab is not None and tab.get("batch") == B and tab.get("samples") == T:
+            krow = next((r for r in tab["kernels"] if r["name"].startswith(lstm_kernel)), None)
+            if krow is not None:
+                traffic = krow["hbm_bytes_per_launch"]
+                traffic_unit = (f"HBM bytes per launch, from {os.path.relpath(PMC_TABLE, ROOT)} (PMC FETCH_SIZE x2 + WRITE_SIZE, "
+                                f"commit {tab.get('commit', '?')})")
+            min_bytes = eng.min_bytes_per_mixture(T) * B
+            whole = {"bytes_per_step": tab["bytes_per_step"], "bytes_per_mixture": round(tab["bytes_per_step"] / B),
+                     "ideal_bytes_per_mixture": round(min_bytes / B), "ratio_to_ideal": round(tab["bytes_per_step"] / min_bytes, 2),
+                     "avg_tb_per_s": round(tab["bytes_per_step"] / (elapsed / args.steps) / 1e12, 3),
+                     "source": f"{os.path.relpath(PMC_TABLE, ROOT)} (sum over kernels x launches per step, commit {tab.get('commit', '?')})"}
         line = {
             "metric": "mixtures/sec (2-spk, 4 s @ 8 kHz) DPTN-AV forward" if args.config == "dptn_av"
                       else f"mixtures/sec {args.config} forward",
@@ -315,8 +375,7 @@ def main():
                        "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": lstm_kernel, "achieved": round(achieved, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": measured_traffic(M * 2 * cfg.num_blocks / launches_per_step),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_lstm_hbm_traffic.json)",
+                         "traffic": traffic, "traffic_unit": traffic_unit,
                          "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (8 * H + 2 * H) * 4,
                          "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
                          "cus_occupied": round(wgs, 1), "frac_of_occupied_cus": round(achieved / (PEAK_F32_MFMA_TFLOPS * cu_share), 4),
@@ -325,9 +384,14 @@ def main():
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},
+            "whole_path_traffic": whole,
             "kernels_ms_per_step": kernels,
             "outputs_finite": finite,
         }
+        if not args.no_train_step:
+            del eng, out
+            torch.cuda.empty_cache()
+            line["train_step"] = train_step_leg(cfg, dev, T)
         if env.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
             line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)

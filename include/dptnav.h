@@ -195,8 +195,8 @@ int dptnav_grad_clip(dptnav_handle h, float* flat_grad, int64_t n_flat, float ma
 /* replaces: torch.optim.AdamW.step()                               src/configs/dptn_wav_av.yaml:9-11, src/trainer/trainer.py:49
  *   Updates IN PLACE the parameters bound with dptnav_bind_weights (those pointers must be writable); flat_grad,
  *   exp_avg, exp_avg_sq: dptnav_flat_numel(h) floats each; step = 1 for the first update (bias correction). */
-int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, float lr,
-                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, double lr,
+                      double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* Test helper: mask (nseq, heads, len, len) fp32 of ones/zeros = the keep-mask of path (block, path). */
 int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, float* mask, void* stream);

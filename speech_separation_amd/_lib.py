@@ -58,7 +58,7 @@ SYMBOLS = {
     "dptnav_tail_scratch_bytes": (_sz, [_vp, _i]),
     "dptnav_pit_sisnr_loss": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i64, C.c_float, _fp, _fp, _fp, _vp, _sz, _vp]),
     "dptnav_grad_clip": (_i, [_vp, _fp, _i64, C.c_float, _vp, _sz, _fp, _vp]),
-    "dptnav_adamw_step": (_i, [_vp, _fp, _fp, _fp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp]),
+    "dptnav_adamw_step": (_i, [_vp, _fp, _fp, _fp, _i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _vp]),
     "dptnav_dropout_mask": (_i, [_vp, _i, _i, _i, _i, _fp, _vp]),
     "dptnav_set_option": (_i, [_vp, C.c_char_p, _i]),
     "dptnav_profile_enable": (_i, [_vp, _i]),

@@ -1432,16 +1432,18 @@ int dptnav_grad_clip(dptnav_handle h, float* flat_grad, int64_t n_flat, float ma
   return DPTNAV_OK;
 }
 
-int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, float lr,
-                      float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_flat, double lr,
+                      double beta1, double beta2, double eps, double weight_decay, int step, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
   if (!h->bound) return h->fail(DPTNAV_ERR_WEIGHTS, "adamw_step: weights not bound (the step updates the bound parameters in place)");
   if (!flat_grad || !exp_avg || !exp_avg_sq || n_flat != dptnav_flat_numel(h) || step < 1)
     return h->fail(DPTNAV_ERR_INVALID, "adamw_step: bad argument (flat buffers must hold %lld floats, step >= 1)",
                    (long long)dptnav_flat_numel(h));
-  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  // hyper-parameters arrive as doubles (Python floats) and every derived constant is formed in double before it is
+  // rounded to fp32 once, as torch does: 1 - 0.999f would already be off by 1.3e-5 relative
+  const double bc1 = 1.0 - std::pow(beta1, step), bc2 = 1.0 - std::pow(beta2, step);
   const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
-  const float decay = (float)(1.0 - (double)lr * weight_decay);
+  const float decay = (float)(1.0 - lr * weight_decay);
   const int n = (int)h->names.size();
   int64_t off = 0;
   for (int lo = 0; lo < n; lo += ADAMW_MAX) {
@@ -1454,7 +1456,8 @@ int dptnav_adamw_step(dptnav_handle h, const float* flat_grad, float* exp_avg, f
       off += (int64_t)align64((size_t)h->numel[lo + e]);
     }
     hipLaunchKernelGGL(adamw_kernel, dim3(cnt, ADAMW_YBLOCKS), dim3(256), 0, (hipStream_t)stream, a, flat_grad, exp_avg, exp_avg_sq,
-                       beta1, (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, decay, step_size, inv_sqrt_bc2);
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, decay, step_size,
+                       inv_sqrt_bc2);
     LAUNCH_CHECK(h, "adamw_step");
   }
   return DPTNAV_OK;
