@@ -213,6 +213,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "train_overlap" (0/1, default 1): run the training step (dptnav_train_forward / _backward) of a batch >= 2 as two
  *                 halves on the two internal streams, like the forward ("overlap" = 0 switches this off too).  Must not
  *                 change between a forward and its backward: the tape layout depends on it.
+ *   "fuse_attn" (0/1, default 1): inference with num_features = 128 runs in-projection + attention + out-projection +
+ *                 LayerNorm 1 of a TransformerDPRNN as ONE kernel when the sequences are <= 160 positions long (QKV and
+ *                 the attention output stay on chip; the "qkv" / "att" workspace taps are then not written); 0 = the three
+ *                 separate launches (always used by the training forward, which keeps qkv / att on the tape).
  *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
  *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
  *   "inject_fail" (n > 0): fault injection for the error-path tests -- the n-th GEMM-engine launch from now on returns

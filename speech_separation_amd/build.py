@@ -19,7 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # then sits out the round trip of a contended atomic every tile, the other waves wait for it at the next barrier).
 SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "lstm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "lstm16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm_bptt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-           "lstm_bptt16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+           "lstm_bptt16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           # attn_block.hip: the softmax works on MFMA results with plain VALU instructions -> accumulators in architectural VGPRs
+           "attn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _headers():

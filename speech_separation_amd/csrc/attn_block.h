@@ -1,0 +1,10 @@
+// attn_block.h -- launcher of the fused attention half of a TransformerDPRNN (attn_block.hip: in-projection, 4-head
+// attention, out-projection, residual and LayerNorm 1 in one kernel; inference, num_features = 128, sequences of at
+// most ATTN_BLOCK_MAX_LEN positions).  Returns a hipError_t as int.
+#pragma once
+#include "common.h"
+
+constexpr int ATTN_BLOCK_MAX_LEN = 160;
+size_t attn_block_lds_bytes();
+int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
+                      const float* gamma, const float* beta, float* y1, const SeqGeom& g);
