@@ -7,7 +7,9 @@
 // path become 1 kB (read x, write y1).  Own translation unit: compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py) so
 // that the score tiles the softmax works on live in architectural VGPRs.
 //
-// One workgroup = one sequence (len <= 160 positions), wave w = head w.  Nothing but partial sums touches LDS:
+// One workgroup = one sequence (len <= 160 positions), wave w = head w.  LDS holds the sequence's token rows (staged once
+// with coalesced loads; every head reads them as MFMA fragments, and the epilogue takes the residual from there) and the
+// out-projection partial sums; Q, K, V, the scores and the attention output never leave the registers:
 //   * K^T and V of the head stay in REGISTERS for the whole sequence (2 x 16 x NKB accumulator registers per lane),
 //     produced directly in the fragment layouts their consumers need:
 //       K^T tile = W_k,h X^T   (A = weight rows, B = token rows)  -> reg r of lane (c,hh) = K[token c][d = ROW32(r,hh)]
@@ -21,7 +23,9 @@
 //   * O^T (reg r = O[query c][d = ROW32(r,hh)]) is the A operand of the head's share of the out-projection,
 //     Y_h = O_h W_o[:, 32h:32h+32]^T; the four heads' partial tiles meet in LDS and the row-space epilogue (bias +
 //     residual + LayerNorm, a row = 32 adjacent lanes) sums them in a fixed order.  No atomics: bit-reproducible.
-// Weights (256 KiB for in- and out-projection) are streamed from L2 per 32-token block; x rows are read twice per head.
+// The head's weight fragments (W_q, W_k, W_v rows and its W_o slice: 4 x 16 KiB per wave) are loaded ONCE per sequence
+// and stay in registers: row-per-lane fragment loads cost the texture path 32 cache lines per wave instruction, and
+// streaming them per token block (first version) made the kernel L1-bound, slower than the three separate launches.
 #include <hip/hip_runtime.h>
 
 #include "attn_block.h"
@@ -29,6 +33,7 @@
 namespace {
 
 constexpr int N = 128, DH = 32;
+constexpr int LDX = N + 4;                  // token rows: conflict-free ds_read_b128 fragments
 constexpr int LDP = 136;                    // partial-tile row stride: rows 4 apart (the two lane halves) are 32 banks apart
 
 DEV float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -47,30 +52,48 @@ DEV float half_sum(float v) {
 
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict__ x, const float* __restrict__ w_in,
-                                                             const float* __restrict__ b_in, const float* __restrict__ w_o,
-                                                             const float* __restrict__ b_o, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ y1, SeqGeom g,
-                                                             float scale_log2e) {
-  extern __shared__ __attribute__((aligned(16))) float P[];   // [4 heads][32 rows][LDP]
+                                                         const float* __restrict__ b_in, const float* __restrict__ w_o,
+                                                         const float* __restrict__ b_o, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y1, SeqGeom g,
+                                                         float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                          // [NKB*32][LDX]  the sequence's token rows (rows >= len repeat the last one)
+  float* P = smem + NKB * 32 * LDX;          // [4 heads][32 rows][LDP]  out-projection partial tiles of one query block
   const int tid = threadIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = head
   const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
   const int seq = blockIdx.x, len = g.len;
   const int64_t tok0 = seq_token_base(g, seq);
   const int tstride = seq_token_stride(g);
-  // the lane's token row of block b (positions beyond len read the last real one: finite, masked / never stored)
-  auto xrow = [&](int b) {
-    const int p = b * 32 + c;
-    return x + (tok0 + (int64_t)(p < len ? p : len - 1) * tstride) * N + 4 * hh;
-  };
-  const float* wq = w_in + (int64_t)(0 * N + h * DH + c) * N + 4 * hh;
-  const float* wk = w_in + (int64_t)(1 * N + h * DH + c) * N + 4 * hh;
-  const float* wv = w_in + (int64_t)(2 * N + h * DH + c) * N + 4 * hh;
+
+  // ---- stage the token rows: coalesced 512-byte rows -> LDS (every wave reads all of them as MFMA fragments) -----
+  {
+    constexpr int NLD = NKB * 4;             // float4 per thread
+    float4 st[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int row = i * 8 + (tid >> 5);
+      st[i] = ldg4(x + (tok0 + (int64_t)(row < len ? row : len - 1) * tstride) * N + 4 * (tid & 31));
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(&Xs[(i * 8 + (tid >> 5)) * LDX + 4 * (tid & 31)]) = st[i];
+  }
+  // ---- this head's weights, resident for the whole sequence: the row-per-lane fragment loads (32 rows x 32 bytes per
+  //      wave instruction) are expensive for the texture path, so they are issued once, not per token block ----------
+  float wkf[64], wvf[64];
+  {
+    const float* wk = w_in + (int64_t)(1 * N + h * DH + c) * N + 4 * hh;
+    const float* wv = w_in + (int64_t)(2 * N + h * DH + c) * N + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 a = ldg4(wk + 8 * m), b = ldg4(wv + 8 * m);
+      wkf[4 * m + 0] = a.x; wkf[4 * m + 1] = a.y; wkf[4 * m + 2] = a.z; wkf[4 * m + 3] = a.w;
+      wvf[4 * m + 0] = b.x; wvf[4 * m + 1] = b.y; wvf[4 * m + 2] = b.z; wvf[4 * m + 3] = b.w;
+    }
+  }
+  __syncthreads();
 
   // ---- phase 1: K^T and V of this head for every key block, kept in registers --------------------------------
-  // Operands stream in chunks of two k-groups (x, W_k, W_v: 6 x 16 bytes per lane and chunk), fetched ONE chunk ahead of
-  // the 16 MFMAs that consume them; the scheduling barriers pin that order -- left alone the scheduler hoists a whole
-  // block's 48 loads (192 registers) to the top and the allocator spills the K^T / V tiles.
   f32x16 kt[NKB], vv[NKB];
   {
     const float bv = b_in[2 * N + h * DH + c];                  // V tile: column d = c
@@ -80,96 +103,94 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       const float4 t = ldg4(b_in + N + h * DH + 8 * j + 4 * hh);
       bk[4 * j + 0] = t.x; bk[4 * j + 1] = t.y; bk[4 * j + 2] = t.z; bk[4 * j + 3] = t.w;
     }
-    constexpr int NCH = 8 * NKB;                                // chunks of the whole phase, across blocks
-    float4 xb[2][2], kb_[2][2], vb[2][2];
-    auto fetch = [&](int ch, int buf) {
-      const int rb = ch >> 3, m0 = 2 * (ch & 7);
-      const float* xr = xrow(rb);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        xb[buf][m] = ldg4(xr + 8 * (m0 + m));
-        kb_[buf][m] = ldg4(wk + 8 * (m0 + m));
-        vb[buf][m] = ldg4(wv + 8 * (m0 + m));
-      }
-    };
-    fetch(0, 0);
-    f32x16 ka = zero16(), va = zero16();
+    for (int rb = 0; rb < NKB; ++rb) {
+      const float* xr = &Xs[(rb * 32 + c) * LDX + 4 * hh];
+      f32x16 ka = zero16(), va = zero16();
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const int buf = ch & 1;
-      if (ch + 1 < NCH) fetch(ch + 1, buf ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int m0 = 0; m0 < 16; m0 += 8) {                      // token-row fragments: two batches of 8 x ds_read_b128
+        float4 xf[8];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float xa[4] = {xb[buf][m].x, xb[buf][m].y, xb[buf][m].z, xb[buf][m].w};
-        const float ka4[4] = {kb_[buf][m].x, kb_[buf][m].y, kb_[buf][m].z, kb_[buf][m].w};
-        const float va4[4] = {vb[buf][m].x, vb[buf][m].y, vb[buf][m].z, vb[buf][m].w};
+        for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const float4*>(xr + 8 * (m0 + m));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {                           // two independent chains
-          ka = mfma32(ka4[t], xa[t], ka);
-          va = mfma32(xa[t], va4[t], va);
+        for (int m = 0; m < 8; ++m) {
+          const float xa[4] = {xf[m].x, xf[m].y, xf[m].z, xf[m].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {                         // two independent chains
+            ka = mfma32(wkf[4 * (m0 + m) + t], xa[t], ka);
+            va = mfma32(xa[t], wvf[4 * (m0 + m) + t], va);
+          }
         }
       }
-      if ((ch & 7) == 7) {                                      // block finished: bias, park the tiles
-        const int rb = ch >> 3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          kt[rb][r] = ka[r] + bk[r];
-          vv[rb][r] = va[r] + bv;
-          // parked in the AGPR half of the register file (one wave per SIMD: 256 + 256 registers per lane); the MFMAs of
-          // phase 2 read their A operand there, the architectural VGPRs stay free for the streaming operands
-          asm volatile("" : "+a"(kt[rb][r]), "+a"(vv[rb][r]));
-        }
-        ka = zero16();
-        va = zero16();
+      for (int r = 0; r < 16; ++r) {
+        kt[rb][r] = ka[r] + bk[r];
+        vv[rb][r] = va[r] + bv;
+        // parked in the AGPR half of the register file (one wave per SIMD: 256 + 256 registers per lane); the MFMAs of
+        // phase 2 read their A operand there
+        asm volatile("" : "+a"(kt[rb][r]), "+a"(vv[rb][r]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // per-lane constants of the row-space epilogue (thread = (row in pass, 4 columns)); re-read per block from L1
+  // ---- phase 2 constants: W_q fragments (A operand, parked in AGPRs), W_o slice of this head (B operand), biases ----
+  float wqf[64];
+  {
+    const float* wq = w_in + (int64_t)(0 * N + h * DH + c) * N + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 a = ldg4(wq + 8 * m);
+      wqf[4 * m + 0] = a.x; wqf[4 * m + 1] = a.y; wqf[4 * m + 2] = a.z; wqf[4 * m + 3] = a.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("" : "+a"(wqf[i]));
+  }
+  float wof[4][16];                                              // W_o[32 jt + c][32 h + ROW32(r,hh)]
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const float* wr = w_o + (int64_t)(32 * jt + c) * N + h * DH + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = ldg4(wr + 8 * j);
+      wof[jt][4 * j + 0] = t.x; wof[jt][4 * j + 1] = t.y; wof[jt][4 * j + 2] = t.z; wof[jt][4 * j + 3] = t.w;
+    }
+  }
+  // row-space epilogue: thread = (row in pass, 4 columns); its per-column constants
   const int c4 = tid & 31, rsub = tid >> 5;
+  const float4 bo = ldg4(b_o + 4 * c4), ga = ldg4(gamma + 4 * c4), be = ldg4(beta + 4 * c4);
+  float qbias[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = ldg4(b_in + h * DH + 8 * j + 4 * hh);
+    qbias[4 * j + 0] = t.x; qbias[4 * j + 1] = t.y; qbias[4 * j + 2] = t.z; qbias[4 * j + 3] = t.w;
+  }
+  float* Pw = P + h * 32 * LDP;
 
   // ---- phase 2: one query block at a time -----------------------------------------------------------------
   for (int qb = 0; qb < NKB; ++qb) {
-    // Q^T tile (operands one chunk ahead, as in phase 1), bias, scale by log2(e)/sqrt(dh)
+    // Q^T tile, bias, scale by log2(e)/sqrt(dh)
     f32x16 q;
     {
-      const float* xr = xrow(qb);
-      float4 xb[2][2], wb[2][2];
-      auto fetch = [&](int ch, int buf) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          xb[buf][m] = ldg4(xr + 8 * (2 * ch + m));
-          wb[buf][m] = ldg4(wq + 8 * (2 * ch + m));
-        }
-      };
-      fetch(0, 0);
+      const float* xr = &Xs[(qb * 32 + c) * LDX + 4 * hh];
       f32x16 q0 = zero16(), q1 = zero16();
 #pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < 8) fetch(ch + 1, buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m0 = 0; m0 < 16; m0 += 8) {
+        float4 xf[8];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          q0 = mfma32(wb[buf][m].x, xb[buf][m].x, q0);
-          q1 = mfma32(wb[buf][m].y, xb[buf][m].y, q1);
-          q0 = mfma32(wb[buf][m].z, xb[buf][m].z, q0);
-          q1 = mfma32(wb[buf][m].w, xb[buf][m].w, q1);
+        for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const float4*>(xr + 8 * (m0 + m));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          q0 = mfma32(wqf[4 * (m0 + m) + 0], xf[m].x, q0);
+          q1 = mfma32(wqf[4 * (m0 + m) + 1], xf[m].y, q1);
+          q0 = mfma32(wqf[4 * (m0 + m) + 2], xf[m].z, q0);
+          q1 = mfma32(wqf[4 * (m0 + m) + 3], xf[m].w, q1);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 t = ldg4(b_in + h * DH + 8 * j + 4 * hh);
-        q[4 * j + 0] = (q0[4 * j + 0] + q1[4 * j + 0] + t.x) * scale_log2e;
-        q[4 * j + 1] = (q0[4 * j + 1] + q1[4 * j + 1] + t.y) * scale_log2e;
-        q[4 * j + 2] = (q0[4 * j + 2] + q1[4 * j + 2] + t.z) * scale_log2e;
-        q[4 * j + 3] = (q0[4 * j + 3] + q1[4 * j + 3] + t.w) * scale_log2e;
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 16; ++r) q[r] = (q0[r] + q1[r] + qbias[r]) * scale_log2e;
     }
+    __builtin_amdgcn_sched_barrier(0);
     // streaming softmax over the key blocks; O^T accumulated transposed (lane = query).  One wave per SIMD: the score
     // tile of block kb+1 is computed between the MFMAs of O^T += V^T P^T of block kb (two independent chains).
     float mrun = -1e30f, lrun = 0.f;
@@ -199,11 +220,12 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       }
       sum = half_sum(sum);
       lrun = lrun * alpha + sum;
-      mrun = mnew;
-      if (kb > 0) {
+      // the running maximum rarely moves after the first blocks: rescale O^T only if some query's did (wave-uniform)
+      if (kb > 0 && __builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
       }
+      mrun = mnew;
       __builtin_amdgcn_sched_barrier(0);
       if (kb + 1 < NKB) {
         s = zero16();
@@ -223,77 +245,51 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] *= inv;
     }
-    // this head's share of the out-projection, two column tiles at a time (two chains; the next pair's weights in
-    // flight): Y_h[query][32 jt + c]
-    float* Pw = P + h * 32 * LDP;
-    {
-      float4 wo[2][2][4];
-      auto fetch = [&](int jp, int buf) {
+    // this head's share of the out-projection, two column tiles at a time (two chains): Y_h[query][32 jt + c]
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float* wr = w_o + (int64_t)(32 * (2 * jp + u) + c) * N + h * DH + 4 * hh;
+    for (int jp = 0; jp < 2; ++jp) {
+      f32x16 ya = zero16(), yb = zero16();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wo[buf][u][j] = ldg4(wr + 8 * j);
-        }
-      };
-      fetch(0, 0);
-#pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
-        if (jp == 0) fetch(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 ya = zero16(), yb = zero16();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ya = mfma32(o[4 * j + 0], wo[jp][0][j].x, ya);
-          yb = mfma32(o[4 * j + 0], wo[jp][1][j].x, yb);
-          ya = mfma32(o[4 * j + 1], wo[jp][0][j].y, ya);
-          yb = mfma32(o[4 * j + 1], wo[jp][1][j].y, yb);
-          ya = mfma32(o[4 * j + 2], wo[jp][0][j].z, ya);
-          yb = mfma32(o[4 * j + 2], wo[jp][1][j].z, yb);
-          ya = mfma32(o[4 * j + 3], wo[jp][0][j].w, ya);
-          yb = mfma32(o[4 * j + 3], wo[jp][1][j].w, yb);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Pw[ROW32(r, hh) * LDP + 32 * (2 * jp) + c] = ya[r];
-          Pw[ROW32(r, hh) * LDP + 32 * (2 * jp + 1) + c] = yb[r];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 16; ++r) {
+        ya = mfma32(o[r], wof[2 * jp][r], ya);
+        yb = mfma32(o[r], wof[2 * jp + 1][r], yb);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        Pw[ROW32(r, hh) * LDP + 32 * (2 * jp) + c] = ya[r];
+        Pw[ROW32(r, hh) * LDP + 32 * (2 * jp + 1) + c] = yb[r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    // row-space epilogue: y1 = LayerNorm(sum_h Y_h + b_o + x); a row = 32 adjacent lanes, 16 bytes per lane
-    {
-      const float4 bo = ldg4(b_o + 4 * c4), ga = ldg4(gamma + 4 * c4), be = ldg4(beta + 4 * c4);
+    // row-space epilogue: y1 = LayerNorm(sum_h Y_h + b_o + x); a row = 32 adjacent lanes, 16 bytes per lane; the residual
+    // row comes from the staged tile
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 8 + rsub;
-        const int p = qb * 32 + row;
-        const bool ok = p < len;
-        const int64_t tok = tok0 + (int64_t)(ok ? p : len - 1) * tstride;
-        const float4 xres = ldg4(x + tok * N + 4 * c4);
-        const float* pr = P + row * LDP + 4 * c4;
-        const float4 a0 = *reinterpret_cast<const float4*>(pr);
-        const float4 a1 = *reinterpret_cast<const float4*>(pr + 32 * LDP);
-        const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
-        const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
-        float4 v;
-        v.x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres.x;
-        v.y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres.y;
-        v.z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres.z;
-        v.w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres.w;
-        const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
-        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-        const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
-        const float rstd = rsqrtf(var + 1e-5f);
-        if (ok) {
-          float4 y;
-          y.x = dx * rstd * ga.x + be.x;
-          y.y = dy * rstd * ga.y + be.y;
-          y.z = dz * rstd * ga.z + be.z;
-          y.w = dw * rstd * ga.w + be.w;
-          *reinterpret_cast<float4*>(y1 + tok * N + 4 * c4) = y;
-        }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 8 + rsub;
+      const int p = qb * 32 + row;
+      const float* pr = P + row * LDP + 4 * c4;
+      const float4 a0 = *reinterpret_cast<const float4*>(pr);
+      const float4 a1 = *reinterpret_cast<const float4*>(pr + 32 * LDP);
+      const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
+      const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
+      const float4 xres = *reinterpret_cast<const float4*>(&Xs[p * LDX + 4 * c4]);
+      float4 v;
+      v.x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres.x;
+      v.y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres.y;
+      v.z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres.z;
+      v.w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres.w;
+      const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
+      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+      const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
+      const float rstd = rsqrtf(var + 1e-5f);
+      if (p < len) {
+        float4 y;
+        y.x = dx * rstd * ga.x + be.x;
+        y.y = dy * rstd * ga.y + be.y;
+        y.z = dz * rstd * ga.z + be.z;
+        y.w = dw * rstd * ga.w + be.w;
+        *reinterpret_cast<float4*>(y1 + (tok0 + (int64_t)p * tstride) * N + 4 * c4) = y;
       }
     }
     __syncthreads();   // the partial tiles are rewritten by the next query block
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
 
 }  // namespace
 
-size_t attn_block_lds_bytes() { return sizeof(float) * 4 * 32 * LDP; }
+size_t attn_block_lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * LDX + 4 * 32 * LDP); }
 
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
                       const float* gamma, const float* beta, float* y1, const SeqGeom& g) {
@@ -320,7 +316,7 @@ int attn_block_launch(void* stream, const float* x, const float* w_in, const flo
   }
   static PerDeviceOnce ready[6];
   const int dev = current_hip_device();
-  const size_t lds = attn_block_lds_bytes();
+  const size_t lds = attn_block_lds_bytes(nkb);
   if (!ready[nkb].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -40,7 +40,7 @@ kernels, total = [], 0.0
 for name, c in acc.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    short = re.sub(r"^void ", "", re.sub(r"\(.*", "", name))
+    short = re.sub(r"^void (\(anonymous namespace\)::)?", "", re.sub(r"\(float.*|\(int.*", "", name))
     if short.startswith(("__amd_rocclr", "at::native")):       # runtime fills / torch helpers: not the path's kernels
         continue
     nf, nw = len(c["FETCH_SIZE"]), len(c["WRITE_SIZE"])
