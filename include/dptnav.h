@@ -217,6 +217,9 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 LayerNorm 1 of a TransformerDPRNN as ONE kernel when the sequences are <= 160 positions long (QKV and
  *                 the attention output stay on chip; the "qkv" / "att" workspace taps are then not written); 0 = the three
  *                 separate launches (always used by the training forward, which keeps qkv / att on the tape).
+ *   "split_bf16" (0/1, default 0): OPT-IN experiment, never a parity claim -- the 16-sequence-tile recurrence of the
+ *                 inference forward runs on bf16 MFMAs with every operand split into bf16 hi + lo (three products, fp32
+ *                 accumulation: ~2^-17 relative error per product instead of 2^-24, ~5x less matrix time); lstm16s.hip.
  *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
  *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
  *   "inject_fail" (n > 0): fault injection for the error-path tests -- the n-th GEMM-engine launch from now on returns

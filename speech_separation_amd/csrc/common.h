@@ -20,10 +20,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DEV __device__ __forceinline__
 
+// ---- split-precision helpers (OPT-IN mode "split_bf16"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) ------------
+// v_mfma_f32_32x32x16_bf16: lane (c = l & 31, hh = l >> 5) holds A[row c][k = 8 hh + j] / B[k = 8 hh + j][col c], j < 8;
+// the accumulator layout is the one of v_mfma_f32_32x32x2_f32 (ROW32), so epilogues do not care which produced it.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+DEV void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
 // row index of accumulator register r (0..15) for half hh in a 32x32 tile
 #define ROW32(r, hh) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hh))
 
 DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+DEV f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 DEV f32x16 zero16() {
   f32x16 z;

@@ -76,6 +76,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
@@ -383,15 +384,15 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
 // The engine is persistent (grid-stride over tiles, weights loaded once per workgroup), so the grid is
 // sized to what is co-resident: CUs x blocks/CU from the occupancy query, queried once per instantiation.
-template <int KIN, int NT, int WR, int WC, bool WT = false, class AL, class EP>
+template <int KIN, int NT, int WR, int WC, bool WT = false, bool SPLIT = false, class AL, class EP>
 int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float* W, int64_t ntiles, int colgroups,
                 const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr) {
   hipStream_t st = run.st;
   if (c->opt_inject_fail > 0 && --c->opt_inject_fail == 0)   // fault injection for the error-path tests (option "inject_fail")
     return c->fail(DPTNAV_ERR_INVALID, "%s: injected failure", what);
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
-  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT>;
-  const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT);
+  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT, SPLIT>;
+  const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT, SPLIT);
   static std::atomic<int> resident_dev[64];  // per instantiation and device (zero-initialised; idempotent fill)
   int resident = resident_dev[c->device_id & 63].load(std::memory_order_acquire);
   if (resident == 0) {
@@ -483,12 +484,16 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   const int nst16 = (geom.nseq + 15) / 16;
   const bool use16 = lstm_use16(c, geom, w.ndir, M);
+  const bool split = c->opt_split_bf16 && !pb.train;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{lstm_in, N, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
     int rc;
-    if (use16) {
+    if (use16 && split) {   // opt-in split-precision mode (bf16 hi/lo operands, fp32 accumulation)
+      EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
+      rc = launch_gemm<N, 4, 1, 4, false, true>(c, run, CAT_LSTM_PRE, "lstm-pre gemm (split)", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+    } else if (use16) {
       EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
       rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
     } else {
@@ -500,7 +505,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
   if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
-  if (use16) {
+  if (use16 && split) {
+    ProfScope ps(c, CAT_LSTM, st);
+    const int rc = lstm16s_launch(c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16s: %s", hipGetErrorString((hipError_t)rc));
+  } else if (use16) {
     // lstm_stamps: diagnostic builds; lstm_diag > 0 are timing-only ablations (wrong results), see lstm16.hip
     const int variant = pb.train ? L16_VARIANT_TRAIN : (c->opt_lstm_stamps ? 1 + c->opt_lstm_diag : 0);
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);   // room: nst16 <= 2 nst
@@ -538,7 +547,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   {
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
     // (training keeps the raw h on the tape and applies ffn[0] = ReLU while loading)
-    if (w.ndir == 2) {
+    if (w.ndir == 2 && split) {
+      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM, pb.train};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC, false, true>(c, run, CAT_FFN, "ffn gemm (split)", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (w.ndir == 2) {
       ALoadCols al{hc, M, 2 * LSTM_H, 0, BM, pb.train};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else {
@@ -1794,6 +1806,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
+  else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
   else if (k == "inject_fail") h->opt_inject_fail = value;

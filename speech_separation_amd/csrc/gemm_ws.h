@@ -82,14 +82,20 @@ struct GemmShape {
   static constexpr int LDA = KIN + 4;      // +4 floats: conflict-free ds_read_b128 fragments
   static constexpr int LDC = WGCOLS + 4;
   static constexpr int KS = KIN / 2;       // MFMA k-steps
-  static constexpr size_t lds_bytes(bool direct) {
-    return sizeof(float) * (4 + 2 * (size_t)BM * LDA + (direct ? 0 : (size_t)BM * LDC));
+  static constexpr int LDAB = KIN + 8;     // split mode: bf16 rows (hi and lo images), conflict-free ds_read_b128
+  static constexpr size_t lds_bytes(bool direct, bool split = false) {
+    // split mode: the double-buffered A tile is two bf16 images (hi, lo) instead of one fp32 image
+    return sizeof(float) * (4 + (split ? 2 * (size_t)BM * LDAB : 2 * (size_t)BM * LDA) + (direct ? 0 : (size_t)BM * LDC));
   }
 };
 
 // WT = true: the B fragments are fetched from W TRANSPOSED, i.e. out[m][j] = sum_k A[m][k] * W[k][j] with W stored
 // [KIN][ldw] -- the data-gradient form of a layer whose forward weight is W[NOUT_fwd = KIN][KIN_fwd = out cols].
-template <int KIN, int NT, int WR, int WC, class ALoad, class Epi, bool WT = false>
+// SPLIT = true (OPT-IN mode "split_bf16", never the default): the product runs on v_mfma_f32_32x32x16_bf16 with both
+// operands split into bf16 hi + lo -- A while it is staged to LDS, W while it is loaded into registers (same register
+// bytes) -- as hi*hi + hi*lo + lo*hi with fp32 accumulation: 24 bf16 MFMAs of 32 cycles replace 64 fp32 ones of 64 per
+// 32x32x128 block.  Accumulator layout, loaders and epilogues are shared with the fp32 form.
+template <int KIN, int NT, int WR, int WC, class ALoad, class Epi, bool WT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ W,
                                                        const float* __restrict__ Walt, int ldw, int ntiles,
                                                        unsigned* __restrict__ tile_queue, ALoad aload, Epi epi) {
@@ -98,7 +104,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_next = reinterpret_cast<int*>(smem);       // [2] tile tickets (double buffered), 16-byte slot
   float* As = smem + 4;
-  float* Cs = As + 2 * Sh::BM * Sh::LDA;
+  float* Cs = As + (SPLIT ? 2 * Sh::BM * Sh::LDAB : 2 * Sh::BM * Sh::LDA);
+  __bf16* Ahi = reinterpret_cast<__bf16*>(As);                 // SPLIT: [2][BM][LDAB] hi image, then the lo image
+  __bf16* Alo = Ahi + 2 * Sh::BM * Sh::LDAB;
+  static_assert(!(SPLIT && WT), "split mode: forward weight layout only");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 31, hh = lane >> 5;
@@ -109,11 +118,27 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   // (Walt != null: column group 1 reads a second weight tensor, e.g. the reverse-direction W_ih)
   const float* Wsel = (Walt != nullptr && colgroup == 1) ? Walt : W;
   const int jbase = Walt != nullptr ? 0 : colgroup * Sh::WGCOLS;
-  float wf[NT][Sh::KS];
+  constexpr int KM = KIN / 16;                       // SPLIT: bf16 MFMAs per product term
+  float wf[SPLIT ? 1 : NT][SPLIT ? 1 : Sh::KS];
+  bf16x8 whi[SPLIT ? NT : 1][SPLIT ? KM : 1], wlo[SPLIT ? NT : 1][SPLIT ? KM : 1];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int j = jbase + (wc * NT + nt) * 32 + c;
-    if constexpr (!WT) {
+    if constexpr (SPLIT) {
+      const float* wrow = Wsel + (int64_t)j * ldw + 8 * hh;
+#pragma unroll
+      for (int m = 0; m < KM; ++m) {
+        const float4 v0 = *reinterpret_cast<const float4*>(wrow + 16 * m), v1 = *reinterpret_cast<const float4*>(wrow + 16 * m + 4);
+        const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          __bf16 hi, lo;
+          split_bf16(xv[e], hi, lo);
+          whi[nt][m][e] = hi;
+          wlo[nt][m][e] = lo;
+        }
+      }
+    } else if constexpr (!WT) {
       const float* wrow = Wsel + (int64_t)j * ldw + 4 * hh;
 #pragma unroll
       for (int m = 0; m < KIN / 8; ++m) {
@@ -151,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   using EpiCols = typename std::conditional<epi_has_cols<Epi>::value, Epi, EpiColsFallback>::type::Cols;
   // (hoisted out of the tile loop unless the kernel is already at its register limit: with KIN = 256 the twelve extra
   //  registers turned into AGPR shuffles inside the loop, +3.6 %, with or without smaller fragment batches)
-  constexpr bool PIN = epi_pins<Epi>::value && NT == 1 && KIN < 256;
+  constexpr bool PIN = !SPLIT && epi_pins<Epi>::value && NT == 1 && KIN < 256;
   constexpr bool HOIST_COLS = epi_has_cols<Epi>::value && !Epi::DIRECT && KIN < 256;
   EpiCols ecols[NPASS];
   if constexpr (HOIST_COLS) {
@@ -191,7 +216,22 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
-      *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
+      if constexpr (SPLIT) {
+        const float xv[4] = {pf[i].x, pf[i].y, pf[i].z, pf[i].w};
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 hi, lo;
+          split_bf16(xv[e], hi, lo);
+          h4[e] = hi;
+          l4[e] = lo;
+        }
+        const int off = buf * (Sh::BM * Sh::LDAB) + (idx / K4) * Sh::LDAB + 4 * (idx % K4);
+        *reinterpret_cast<bf16x4*>(&Ahi[off]) = h4;
+        *reinterpret_cast<bf16x4*>(&Alo[off]) = l4;
+      } else {
+        *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
+      }
     }
     GEMM_STAMP(0);     // (diagnostic builds: phase 0 = ticket + A tile -> LDS, phase 1 = the barrier)
     __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
@@ -222,7 +262,23 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
     f32x16 acc_odd = zero16();   // (PIN only)
-    {
+    if constexpr (SPLIT) {
+      const int rowoff = buf * (Sh::BM * Sh::LDAB) + (wr * 32 + c) * Sh::LDAB + 8 * hh;
+      bf16x8 ah[KM], al[KM];
+#pragma unroll
+      for (int m = 0; m < KM; ++m) {
+        ah[m] = *reinterpret_cast<const bf16x8*>(&Ahi[rowoff + 16 * m]);
+        al[m] = *reinterpret_cast<const bf16x8*>(&Alo[rowoff + 16 * m]);
+      }
+#pragma unroll
+      for (int m = 0; m < KM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[nt] = mfma32_bf16(ah[m], whi[nt][m], acc[nt]);
+          acc[nt] = mfma32_bf16(ah[m], wlo[nt][m], acc[nt]);
+          acc[nt] = mfma32_bf16(al[m], whi[nt][m], acc[nt]);
+        }
+    } else {
       // fragments are fetched in batches of 16 x ds_read_b128 BEFORE the MFMAs that use them: a read placed
       // between MFMAs is followed by s_waitcnt lgkmcnt(0) and exposes a full LDS round trip per k-chunk
       const float* arow = &Ab[(wr * 32 + c) * Sh::LDA + 4 * hh];

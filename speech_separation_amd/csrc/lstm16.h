@@ -38,3 +38,8 @@ constexpr int L16_VARIANT_TRAIN = 7;
 int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
                   const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, unsigned long long* stamps,
                   float* tape_gates = nullptr, float* tape_c = nullptr);
+
+// OPT-IN split-precision variant (lstm16s.hip, option "split_bf16"): the recurrent product on bf16 MFMAs with every
+// operand split into bf16 hi + lo (3 products, fp32 accumulation); same PRE16 input, same fp32 output.  Inference only.
+int lstm16s_launch(bool relu, int nst16, int ndir, void* stream, const float* pre, const float* whh_f, const float* whh_b,
+                   float* hc, int ldh, int dump_row, const SeqGeom& g);
