@@ -7,4 +7,4 @@
 constexpr int ATTN_BLOCK_MAX_LEN = 160;
 size_t attn_block_lds_bytes(int nkb);
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
-                      const float* gamma, const float* beta, float* y1, const SeqGeom& g);
+                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split = false);

@@ -296,27 +296,303 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   }
 }
 
+
+// =====================================================================================================================
+// OPT-IN split-precision variant (option "split_bf16"; never the default, never a parity claim): the same kernel on
+// v_mfma_f32_32x32x16_bf16 with every operand split into bf16 hi + lo (x = hi + lo to 16 significant bits) and each
+// product formed as hi*hi + hi*lo + lo*hi with fp32 accumulation -- 3 bf16 MFMAs of 32 cycles replace 8 fp32 MFMAs of
+// 64.  The accumulator layout of the bf16 instruction is the fp32 one's (ROW32), and its operand fragment (lane (c,hh)
+// holds elements k = 8hh + j, j < 8) is filled with accumulator registers 8mm .. 8mm+7 of the producing tile: element
+// (hh, j) then means d (or key) ROW32(8mm + j, hh) in BOTH operands of the consuming product, which is all a
+// contraction needs.  So the register-resident chain of the fp32 kernel carries over: K^T / V tiles are parked as bf16
+// hi / lo packs (16 registers per tile, as before), Q^T, the probabilities and O^T are split on the fly.  Token rows are
+// staged in LDS as two bf16 images; the residual of the epilogue is re-read from global memory in fp32.
+DEV void split_tile(const f32x16& t, bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
+#pragma unroll
+  for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 h, l;
+      split_bf16(t[8 * mm + j], h, l);
+      hi[mm][j] = h;
+      lo[mm][j] = l;
+    }
+}
+DEV void split_row8(const float* p, bf16x8& hi, bf16x8& lo) {     // 8 consecutive floats (two 16-byte loads)
+  const float4 v0 = ldg4(p), v1 = ldg4(p + 4);
+  const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    __bf16 h, l;
+    split_bf16(xv[e], h, l);
+    hi[e] = h;
+    lo[e] = l;
+  }
+}
+// three-term product on split operands
+DEV f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 c) {
+  c = mfma32_bf16(ah, bh, c);
+  c = mfma32_bf16(ah, bl, c);
+  return mfma32_bf16(al, bh, c);
+}
+
+constexpr int LDXB = N + 8;                 // bf16 token rows (272 bytes): conflict-free ds_read_b128 fragments
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_block_split_kernel(const float* __restrict__ x, const float* __restrict__ w_in,
+                                                               const float* __restrict__ b_in, const float* __restrict__ w_o,
+                                                               const float* __restrict__ b_o, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y1, SeqGeom g,
+                                                               float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* P = smem;                                                     // [4 heads][32 rows][LDP] fp32 partial tiles
+  __bf16* Xhi = reinterpret_cast<__bf16*>(smem + 4 * 32 * LDP);        // [NKB*32][LDXB]
+  __bf16* Xlo = Xhi + NKB * 32 * LDXB;
+  const int tid = threadIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 6);              // wave = head
+  const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int seq = blockIdx.x, len = g.len;
+  const int64_t tok0 = seq_token_base(g, seq);
+  const int tstride = seq_token_stride(g);
+
+  // ---- stage the token rows as bf16 hi / lo images -----------------------------------------------------------
+  {
+    constexpr int NLD = NKB * 4;
+    float4 st[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int row = i * 8 + (tid >> 5);
+      st[i] = ldg4(x + (tok0 + (int64_t)(row < len ? row : len - 1) * tstride) * N + 4 * (tid & 31));
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const float xv[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+      bf16x4 h4, l4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 hv, lv;
+        split_bf16(xv[e], hv, lv);
+        h4[e] = hv;
+        l4[e] = lv;
+      }
+      const int off = (i * 8 + (tid >> 5)) * LDXB + 4 * (tid & 31);
+      *reinterpret_cast<bf16x4*>(&Xhi[off]) = h4;
+      *reinterpret_cast<bf16x4*>(&Xlo[off]) = l4;
+    }
+  }
+  // ---- this head's K / V weight fragments (k = 16m + 8hh + j), resident for phase 1 ------------------------------
+  bf16x8 wkh[8], wkl[8], wvh[8], wvl[8];
+  {
+    const float* wk = w_in + (int64_t)(1 * N + h * DH + c) * N + 8 * hh;
+    const float* wv = w_in + (int64_t)(2 * N + h * DH + c) * N + 8 * hh;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      split_row8(wk + 16 * m, wkh[m], wkl[m]);
+      split_row8(wv + 16 * m, wvh[m], wvl[m]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: K^T and V tiles of every key block, parked as bf16 hi / lo packs --------------------------------
+  bf16x8 kth[NKB][2], ktl[NKB][2], vvh[NKB][2], vvl[NKB][2];
+  {
+    const float bv = b_in[2 * N + h * DH + c];
+    float bk[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = ldg4(b_in + N + h * DH + 8 * j + 4 * hh);
+      bk[4 * j + 0] = t.x; bk[4 * j + 1] = t.y; bk[4 * j + 2] = t.z; bk[4 * j + 3] = t.w;
+    }
+#pragma unroll
+    for (int rb = 0; rb < NKB; ++rb) {
+      const int roff = (rb * 32 + c) * LDXB + 8 * hh;
+      f32x16 ka = zero16(), va = zero16();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&Xhi[roff + 16 * m]);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&Xlo[roff + 16 * m]);
+        ka = mfma3(wkh[m], wkl[m], xh, xl, ka);         // K^T = W_k X^T: A = weight rows, B = token rows
+        va = mfma3(xh, xl, wvh[m], wvl[m], va);         // V   = X W_v^T
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ka[r] += bk[r];
+        va[r] += bv;
+      }
+      split_tile(ka, kth[rb], ktl[rb]);
+      split_tile(va, vvh[rb], vvl[rb]);
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) asm volatile("" : "+a"(kth[rb][mm]), "+a"(ktl[rb][mm]), "+a"(vvh[rb][mm]), "+a"(vvl[rb][mm]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- phase 2 constants ------------------------------------------------------------------------------------
+  bf16x8 wqh[8], wql[8];
+  {
+    const float* wq = w_in + (int64_t)(0 * N + h * DH + c) * N + 8 * hh;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      split_row8(wq + 16 * m, wqh[m], wql[m]);
+      asm volatile("" : "+a"(wqh[m]), "+a"(wql[m]));
+    }
+  }
+  bf16x8 woh[4][2], wol[4][2];                         // W_o[32 jt + c][32 h + ROW32(8 mm + j, hh)]
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    const float* wr = w_o + (int64_t)(32 * jt + c) * N + h * DH + 4 * hh;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+      const float4 v0 = ldg4(wr + 16 * mm), v1 = ldg4(wr + 16 * mm + 8);
+      const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 hv, lv;
+        split_bf16(xv[e], hv, lv);
+        woh[jt][mm][e] = hv;
+        wol[jt][mm][e] = lv;
+      }
+    }
+  }
+  const int c4 = tid & 31, rsub = tid >> 5;
+  const float4 bo = ldg4(b_o + 4 * c4), ga = ldg4(gamma + 4 * c4), be = ldg4(beta + 4 * c4);
+  float qbias[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = ldg4(b_in + h * DH + 8 * j + 4 * hh);
+    qbias[4 * j + 0] = t.x; qbias[4 * j + 1] = t.y; qbias[4 * j + 2] = t.z; qbias[4 * j + 3] = t.w;
+  }
+  float* Pw = P + h * 32 * LDP;
+
+  for (int qb = 0; qb < NKB; ++qb) {
+    // the fp32 residual rows of this block's epilogue: requested now, used after the out-projection
+    float4 xres[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int p = qb * 32 + pass * 8 + rsub;
+      xres[pass] = ldg4(x + (tok0 + (int64_t)(p < len ? p : len - 1) * tstride) * N + 4 * c4);
+    }
+    // Q^T tile, bias, scale, split
+    bf16x8 qh[2], ql[2];
+    {
+      const int roff = (qb * 32 + c) * LDXB + 8 * hh;
+      f32x16 q = zero16();
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(&Xhi[roff + 16 * m]);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&Xlo[roff + 16 * m]);
+        q = mfma3(wqh[m], wql[m], xh, xl, q);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q[r] = (q[r] + qbias[r]) * scale_log2e;
+      split_tile(q, qh, ql);
+    }
+    float mrun = -1e30f, lrun = 0.f;
+    f32x16 o = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      f32x16 s = zero16();
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) s = mfma3(kth[kb][mm], ktl[kb][mm], qh[mm], ql[mm], s);   // S^T[key][query]
+      if (kb == NKB - 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + ROW32(r, hh) >= len) s[r] = -1e30f;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = half_max(mx);
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = fast_exp2(mrun - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = fast_exp2(s[r] - mnew);
+        sum += s[r];
+      }
+      sum = half_sum(sum);
+      lrun = lrun * alpha + sum;
+      if (kb > 0 && __builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+      }
+      mrun = mnew;
+      bf16x8 ph[2], pl[2];
+      split_tile(s, ph, pl);
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) o = mfma3(vvh[kb][mm], vvl[kb][mm], ph[mm], pl[mm], o);   // O^T[d][query]
+    }
+    {
+      const float inv = fast_rcp(lrun);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= inv;
+    }
+    bf16x8 oh[2], ol[2];
+    split_tile(o, oh, ol);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      f32x16 ya = zero16();
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) ya = mfma3(oh[mm], ol[mm], woh[jt][mm], wol[jt][mm], ya);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Pw[ROW32(r, hh) * LDP + 32 * jt + c] = ya[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 8 + rsub;
+      const int p = qb * 32 + row;
+      const float* pr = P + row * LDP + 4 * c4;
+      const float4 a0 = *reinterpret_cast<const float4*>(pr);
+      const float4 a1 = *reinterpret_cast<const float4*>(pr + 32 * LDP);
+      const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
+      const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
+      float4 v;
+      v.x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres[pass].x;
+      v.y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres[pass].y;
+      v.z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres[pass].z;
+      v.w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres[pass].w;
+      const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
+      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+      const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
+      const float rstd = rsqrtf(var + 1e-5f);
+      if (p < len) {
+        float4 y;
+        y.x = dx * rstd * ga.x + be.x;
+        y.y = dy * rstd * ga.y + be.y;
+        y.z = dz * rstd * ga.z + be.z;
+        y.w = dw * rstd * ga.w + be.w;
+        *reinterpret_cast<float4*>(y1 + (tok0 + (int64_t)p * tstride) * N + 4 * c4) = y;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 size_t attn_block_lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * LDX + 4 * 32 * LDP); }
 
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
-                      const float* gamma, const float* beta, float* y1, const SeqGeom& g) {
+                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split) {
   using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                         SeqGeom, float);
   Kern kern;
   const int nkb = (g.len + 31) / 32;
   switch (nkb) {
-    case 1: kern = attn_block_kernel<1>; break;
-    case 2: kern = attn_block_kernel<2>; break;
-    case 3: kern = attn_block_kernel<3>; break;
-    case 4: kern = attn_block_kernel<4>; break;
-    case 5: kern = attn_block_kernel<5>; break;
+    case 1: kern = split ? attn_block_split_kernel<1> : attn_block_kernel<1>; break;
+    case 2: kern = split ? attn_block_split_kernel<2> : attn_block_kernel<2>; break;
+    case 3: kern = split ? attn_block_split_kernel<3> : attn_block_kernel<3>; break;
+    case 4: kern = split ? attn_block_split_kernel<4> : attn_block_kernel<4>; break;
+    case 5: kern = split ? attn_block_split_kernel<5> : attn_block_kernel<5>; break;
     default: return (int)hipErrorInvalidValue;
   }
-  static PerDeviceOnce ready[6];
+  static PerDeviceOnce ready_all[2][6];
+  PerDeviceOnce* ready = ready_all[split ? 1 : 0];
   const int dev = current_hip_device();
-  const size_t lds = attn_block_lds_bytes(nkb);
+  // (the split variant keeps two bf16 images of the token rows: 2 x 272 bytes per row instead of 528)
+  const size_t lds = split ? sizeof(float) * 4 * 32 * LDP + sizeof(__bf16) * 2 * (size_t)nkb * 32 * LDXB : attn_block_lds_bytes(nkb);
   if (!ready[nkb].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

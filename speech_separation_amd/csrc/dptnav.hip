@@ -462,7 +462,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const bool fused = dptn && !pb.train && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && g.num_heads == 4;
   if (fused) {
     ProfScope ps(c, CAT_ATTN, st);
-    const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom);
+    const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention block: %s", hipGetErrorString((hipError_t)rc));
   }
   // K1: qkv = x W_in^T + b_in                                  (nn.MultiheadAttention in-projection)
