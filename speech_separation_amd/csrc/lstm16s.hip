@@ -7,11 +7,17 @@
 // accumulation: 3 bf16 MFMAs replace 8 fp32 ones, ~5x less matrix time at ~2^-17 relative error per product (fp32:
 // 2^-24).  W_hh costs the same 256 registers per lane as in fp32 (two bf16 per register).  Everything else is
 // lstm16.hip's design: one workgroup = one direction x 16 sequences, W_hh resident in AGPRs as B fragments,
-// pre-activations (fp32, PRE16 layout, pre-scaled) delivered by LDS-DMA one step ahead, lane-local cell update in
-// fp32, one barrier per step.  h_t is exchanged through LDS three times over: fp32 rows (they leave for HBM as 16-byte
+// pre-activations (fp32, PRE16 layout, pre-scaled), lane-local cell update in fp32, one barrier per step.  The split
+// step takes ~2 us -- about one HBM round trip -- so the pre-activations are fetched TWO steps ahead, straight into the
+// registers that will be that step's accumulators (the PRE16 layout hands every lane its own 16 bytes; three accumulator
+// sets rotate, the step loop is unrolled by three): the compiler then counts the outstanding loads exactly, whereas any
+// LDS access behind an LDS-DMA makes it wait for ALL of them (s_waitcnt vmcnt(0)), which pins the prefetch distance of
+// lstm16.hip's scheme to one step.  h_t is exchanged through LDS three times over: fp32 rows (they leave for HBM as 16-byte
 // row pieces, full precision) and the bf16 hi / lo images the next step's A fragments are read from (ds_read_b128 =
 // 8 consecutive k of one sequence row = one fragment of v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][8(l>>4)+j]).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "lstm16.h"
 
@@ -22,6 +28,7 @@ namespace {
 
 constexpr int LDB = L16_H + 8;                         // bf16 row stride (272 bytes): conflict-free ds_read_b128 fragments
 constexpr int HB_ELEMS = 2 * 16 * LDB;                 // one bf16 image, double buffered
+
 
 DEV f32x4v mfma_bf16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
@@ -38,8 +45,7 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
                                                       int dump_row, SeqGeom g, int nst16) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                                              // fp32 [2][16][L16_LDH]
-  float* Ps = smem + L16_HS_FLOATS;                              // [4][8][256]
-  __bf16* Hhi = reinterpret_cast<__bf16*>(smem + L16_HS_FLOATS + L16_PRE_FLOATS);   // [2][16][LDB]
+  __bf16* Hhi = reinterpret_cast<__bf16*>(smem + L16_HS_FLOATS);   // [2][16][LDB]
   __bf16* Hlo = Hhi + HB_ELEMS;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,33 +95,23 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
   f32x4v cst[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
 
   const float* pre_lane = pre + pre16_tile_offset(d, st, 0, nst16, g.len) + (int64_t)w * 2048 + lane * 4;
-  float* ps_wave = Ps + w * 2048;
-  auto issue_pre_piece = [&](const float* p, int piece) {   // compile-time after unrolling
-    const int hi = piece >> 2;
-    switch (piece & 3) {
-      case 0: glds16_off<0>(p + hi * 1024, ps_wave + hi * 1024); break;
-      case 1: glds16_off<1024>(p + hi * 1024, ps_wave + hi * 1024); break;
-      case 2: glds16_off<2048>(p + hi * 1024, ps_wave + hi * 1024); break;
-      default: glds16_off<3072>(p + hi * 1024, ps_wave + hi * 1024); break;
-    }
+  auto tile_of = [&](int step) { return pre_lane + (int64_t)(t0 + tdir * (step < g.len ? step : g.len - 1)) * L16_TILE_FLOATS; };
+  // three accumulator sets: step s accumulates in X[s % 3]; the loads of step s + 2 land in X[(s + 2) % 3]
+  f32x4v X[3][8];
+  auto fetch_piece = [&](f32x4v (&dst)[8], const float* tile, int b) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + b * 256);
+    dst[b] = (f32x4v){v.x, v.y, v.z, v.w};
   };
 #pragma unroll
-  for (int piece = 0; piece < 8; ++piece) issue_pre_piece(pre_lane + (int64_t)t0 * L16_TILE_FLOATS, piece);
+  for (int b = 0; b < 8; ++b) fetch_piece(X[0], tile_of(0), b);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) fetch_piece(X[1], tile_of(1), b);
   __syncthreads();
 
-  f32x4v acc[8];
-  auto preload_acc = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const float4 v = *reinterpret_cast<const float4*>(ps_wave + b * 256 + lane * 4);
-      acc[b] = (f32x4v){v.x, v.y, v.z, v.w};
-    }
-  };
-  preload_acc();
-
-  for (int step = 0; step < g.len; ++step) {
-    const int t = t0 + tdir * step;
+  auto step_body = [&](auto ring, int step) {
+    constexpr int R = decltype(ring)::value;
+    f32x4v (&acc)[8] = X[R];
+    f32x4v (&nxt2)[8] = X[(R + 2) % 3];
     const int cur = step & 1, nxt = cur ^ 1;
     const float* hcur = Hs + cur * 16 * L16_LDH;
     float* hnext = Hs + nxt * 16 * L16_LDH;
@@ -136,10 +132,8 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
     float4 hs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
-
-    const float* pnext = pre_lane + (int64_t)(step + 1 < g.len ? t + tdir : t) * L16_TILE_FLOATS;
+    // branch-free: beyond the last step the requests re-read the last tile into a set nobody uses any more
+    const float* pnext = tile_of(step + 2);
     const unsigned adv = step > 0 ? sstep : 0u;
 
     auto cell_half = [&](int hf) {
@@ -172,22 +166,30 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
           acc[b] = mfma_bf16(ahi[m], whi[b][m], acc[b]);
           acc[b] = mfma_bf16(ahi[m], wlo[b][m], acc[b]);
           acc[b] = mfma_bf16(alo[m], whi[b][m], acc[b]);
-          // one memory instruction per MFMA group: the two row stores of h_{t-1}, then the eight LDS-DMA requests
+          // one memory instruction per MFMA group: the two row stores of h_{t-1}, then the eight pre-activation loads of
+          // step + 2
           const int slot = 4 * m + gt;
           if (hf == 0 && slot < 2) {
             if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
             *reinterpret_cast<float4*>(hcb + soff[slot]) = hs[slot];
             soff[slot] += adv;
           } else if (hf == 0 && slot < 10) {
-            issue_pre_piece(pnext, slot - 2);
+            fetch_piece(nxt2, pnext, slot - 2);
           }
         }
       }
       if (hf == 0) cell_half(0);
     }
     cell_half(1);
-    if (step + 1 < g.len) preload_acc();
     __syncthreads();
+  };
+  for (int step = 0; step < g.len;) {
+    step_body(std::integral_constant<int, 0>{}, step);
+    if (++step >= g.len) break;
+    step_body(std::integral_constant<int, 1>{}, step);
+    if (++step >= g.len) break;
+    step_body(std::integral_constant<int, 2>{}, step);
+    ++step;
   }
   // h of the last step: the barrier above published it in buffer (len & 1)
   {
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
   }
 }
 
-constexpr size_t LDS_BYTES = L16_LDS_BYTES + sizeof(__bf16) * 2 * HB_ELEMS;
+constexpr size_t LDS_BYTES = sizeof(float) * L16_HS_FLOATS + sizeof(__bf16) * 2 * HB_ELEMS;
 
 }  // namespace
 
