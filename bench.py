@@ -202,6 +202,12 @@ def bench_train(args, env, cfg, B, T, workload):
     env.barrier()
     torch.cuda.synchronize(dev)
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    if args.pmc_run:
+        if env.rank == 0:
+            print(json.dumps({"pmc_run": True, "config": args.config, "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3)}),
+                  flush=True)
+        env.close()
+        return
     eng = model._engine
     eng.profile(True)
     eng.profile_reset()

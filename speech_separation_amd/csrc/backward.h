@@ -40,17 +40,20 @@ struct ALoadSeqShift {
   }
 };
 
-// dense rows of a column slice [col0, col0 + width) of a token-major matrix
-struct ALoadCols {
+// dense rows of a column slice [col0, col0 + width) of a token-major matrix.  RELU (ffn[0] applied while loading the raw
+// LSTM output the training tape keeps) is a COMPILE-TIME flag: as a runtime member it put a branch behind every load, the
+// loads of a tile could no longer be issued as one batch, and the K = 256 GEMMs of the training step ran 1.6x longer
+// than the same instantiation in inference (rocprofv3 PMC pass: 552 k vs 341 k active cycles per launch).
+template <bool RELU>
+struct ALoadColsT {
   const float* A;
   int64_t M;
   int lda, col0, bm;
-  bool relu;
   DEV float4 load4(int tile, int row, int k4) const {
     const int64_t r0 = (int64_t)tile * bm;
     if (r0 + row >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
     float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)(row * lda + col0 + 4 * k4));
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
   }
   // GEMM-engine form (rows beyond M are never stored there): clamped, branch-free.  The weight-gradient kernels need
@@ -59,10 +62,12 @@ struct ALoadCols {
     const int64_t r0 = (int64_t)tile * bm;
     const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);
     float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((row < last ? row : last) * lda + col0 + 4 * k4));
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
   }
 };
+using ALoadCols = ALoadColsT<false>;
+using ALoadColsReLU = ALoadColsT<true>;
 
 template <int NN, int KK>
 struct WgradShape {

@@ -41,12 +41,16 @@ struct EpiDecoderBwd {
     const int t = (int)(rem - (int64_t)bb * L);
     const float* dy = (spk ? dy2 : dy1) + (int64_t)bb * T;
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < kenc; ++j) {
+    // (taps unrolled to the table width with a predicate: a runtime trip count made wacc[i][j] a dynamically indexed
+    //  array, i.e. 232 bytes of scratch per lane and 0.07 MFMA-busy for the whole launch)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool tap = j < kenc;
       const int64_t n = (int64_t)pad_left + (int64_t)stride * t + j;
-      const float d = (n >= 0 && n < T) ? dy[n] : 0.f;
+      const float d = (tap && n >= 0 && n < T) ? dy[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        dq[i] = fmaf(d, wdec[(4 * c4 + i) * kenc + j], dq[i]);
+        dq[i] = fmaf(d, tap ? wdec[(4 * c4 + i) * kenc + j] : 0.f, dq[i]);
         wacc[i][j] = fmaf(q[i], d, wacc[i][j]);
       }
     }

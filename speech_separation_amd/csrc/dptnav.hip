@@ -548,13 +548,19 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
     // (training keeps the raw h on the tape and applies ffn[0] = ReLU while loading)
     if (w.ndir == 2 && split) {
-      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM, pb.train};
+      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC, false, true>(c, run, CAT_FFN, "ffn gemm (split)", w.ffn_w, ntiles, 1, al, ep)) return rc;
-    } else if (w.ndir == 2) {
-      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM, pb.train};
+    } else if (w.ndir == 2 && pb.train) {
+      ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (w.ndir == 2) {
+      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (pb.train) {
+      ALoadColsReLU al{hc, M, LSTM_H, 0, BM};
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else {
-      ALoadCols al{hc, M, LSTM_H, 0, BM, pb.train};
+      ALoadCols al{hc, M, LSTM_H, 0, BM};
       if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     }
   }
@@ -783,7 +789,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
 
   // 1. recompute z2 = relu(h) W_f^T + b_f + y1 and push d_out through LayerNorm 2
   {
-    ALoadCols al{hc, M, 2 * LSTM_H, 0, 32, true};
+    ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, 32};
     EpiLNBackward<GROUP, 0> ep{DZ, w.ffn_b, y1, w.ln2_w, d_out, LNP, M, N, 32};
     if (int rc = launch_gemm<2 * LSTM_H, 1, 1, 4>(c, run, CAT_FFN, "ffn recompute + ln2 bwd", w.ffn_w, ntiles, 1, al, ep,
                                                  nullptr, 2 * LSTM_H, &grid))
@@ -796,8 +802,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   br.slot = run.slot;
   // 2. ffn parameter gradients
   {
-    ALoadCols yl{DZ, M, N, 0, 32, false};
-    ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32, true};
+    ALoadCols yl{DZ, M, N, 0, 32};
+    ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
     if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
       return rc;
   }
@@ -805,7 +811,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   {
     ALoadDense al{DZ, M, N, 32};
-    EpiAddMaskStore ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+    EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
     if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
       return rc;
   }
@@ -837,7 +843,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     ALoadDense xl{y1, M, N, 32};
     ALoadSeqShift hl{hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom};
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
-      ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32, false};
+      ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
       if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
       if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
     }
@@ -845,8 +851,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
   run.slot = br.slot;
   for (int d = 0; d < 2; ++d) {
-    ALoadCols al{DG, M, 2 * 512, d * 512, 32, false};
-    EpiAddMaskStore ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
+    ALoadCols al{DG, M, 2 * 512, d * 512, 32};
+    EpiAddMaskStoreT<true, false> ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
     if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
       return rc;
   }
@@ -865,7 +871,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   br.slot = run.slot;
   // 8. out-projection gradients and d att
   {
-    ALoadCols yl{DZ, M, N, 0, 32, false};
+    ALoadCols yl{DZ, M, N, 0, 32};
     ALoadDense xl{att, M, N, 32};
     if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
                                     G("mha.out_proj.bias")))
@@ -874,7 +880,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   {
     ALoadDense al{DZ, M, N, 32};
-    EpiAddMaskStore ep{DATT, nullptr, nullptr, M, N, 32, N};
+    EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
     if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles, 1, al, ep, nullptr, N)) return rc;
   }
   br.slot = run.slot;
@@ -914,7 +920,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   // 10. in-projection gradients and d x = dz1 (residual) + dqkv W_in
   {
-    ALoadCols yl{DQKV, M, 3 * N, 0, 32, false};
+    ALoadCols yl{DQKV, M, 3 * N, 0, 32};
     ALoadDense xl{x_in, M, N, 32};
     if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight + bias", ntiles, yl, xl, G("mha.in_proj_weight"),
                                         G("mha.in_proj_bias")))
@@ -923,7 +929,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   {
     ALoadDense al{DQKV, M, 3 * N, 32};
-    EpiAddMaskStore ep{d_in, DZ, nullptr, M, N, 32, N};
+    EpiAddMaskStoreT<true, false> ep{d_in, DZ, nullptr, M, N, 32, N};
     if (int rc = launch_gemm<3 * N, 1, 1, 4, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles, 1, al, ep, nullptr, N)) return rc;
   }
   br.slot = run.slot;
@@ -989,7 +995,7 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   // post-processing conv gradients; d u = d q W_post
   if (int rc = launch_colsum<N>(c, br, "d postproc bias", DQ, rows, N, 0, G("dprnn.postprocessing.0.bias"))) return rc;
   {
-    ALoadCols yl{DQ, rows, N, 0, 32, false};
+    ALoadCols yl{DQ, rows, N, 0, 32};
     ALoadOla xl{Z, N, B, (int)L, S, K, P, left, ola, 32};
     if (int rc = launch_wgrad<N, N>(c, br, "d postproc weight", (rows + 31) / 32, yl, xl, G("dprnn.postprocessing.0.weight")))
       return rc;
@@ -997,7 +1003,7 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   run.slot = br.slot;
   {
     ALoadDense al{DQ, rows, N, 32};
-    EpiAddMaskStore ep{DU, nullptr, nullptr, rows, N, 32, N};
+    EpiAddMaskStoreT<false, false> ep{DU, nullptr, nullptr, rows, N, 32, N};
     if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_POST, "d u", c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32,
                                               1, al, ep, nullptr, N))
       return rc;
@@ -1008,7 +1014,7 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   LAUNCH_CHECK(c, "ola backward");
   if (int rc = launch_colsum<2 * N>(c, br, "d sep bias", DZs, M, 2 * N, 0, G("dprnn.speakers_separation.1.bias"))) return rc;
   {
-    ALoadCols yl{DZs, M, 2 * N, 0, 32, false};
+    ALoadCols yl{DZs, M, 2 * N, 0, 32};
     ALoadDensePReLU xl{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
     if (int rc = launch_wgrad<2 * N, N>(c, br, "d sep weight", (M + 31) / 32, yl, xl, G("dprnn.speakers_separation.1.weight")))
       return rc;

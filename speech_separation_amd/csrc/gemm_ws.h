@@ -632,26 +632,30 @@ struct ALoadDenseReLU {
   }
 };
 
-// out[row][col] = (v + addend[row][col]) * (gate[row][col] > 0 ? 1 : 0); addend / gate may be null
-struct EpiAddMaskStore {
+// out[row][col] = (v + addend[row][col]) * (gate[row][col] > 0 ? 1 : 0).  Which of the two operands exist is a
+// COMPILE-TIME property (ADD, GATE): as null checks at run time they put branches into the prefetches and the engine's
+// operand loads could not be issued as one batch (0.32 MFMA-busy on the d h launch).
+template <bool ADD, bool GATE>
+struct EpiAddMaskStoreT {
   static constexpr bool DIRECT = false;
   static constexpr bool HAS_FINISH = false;
   float* out;
-  const float* addend;   // [M][ldo] or null
-  const float* gate;     // [M][ldo] or null: ReLU mask source (forward activation)
+  const float* addend;   // [M][ldo] (ADD)
+  const float* gate;     // [M][ldo] (GATE): ReLU mask source (forward activation)
   int64_t M;
   int ldo;
   int bm;
   int wgcols;
   DEV int last_row(int64_t r0) const { return (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1); }   // wave-uniform
   DEV float4 prefetch(int tile, int row, int c4) const {   // (single column group only when an addend / gate is given)
-    if (addend == nullptr) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!ADD) return make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t r0 = (int64_t)tile * bm;
     const int last = last_row(r0);
     return *reinterpret_cast<const float4*>(addend + r0 * ldo + (unsigned)((row < last ? row : last) * ldo + 4 * c4));
   }
+  DEV float4 prefetchc(int tile, int row, int c4) const { return prefetch(tile, row, c4); }
   DEV float4 prefetch2(int tile, int row, int c4) const {   // the ReLU-mask source row
-    if (gate == nullptr) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (!GATE) return make_float4(1.f, 1.f, 1.f, 1.f);
     const int64_t r0 = (int64_t)tile * bm;
     const int last = last_row(r0);
     return *reinterpret_cast<const float4*>(gate + r0 * ldo + (unsigned)((row < last ? row : last) * ldo + 4 * c4));
@@ -659,8 +663,10 @@ struct EpiAddMaskStore {
   DEV void row(int tile, int row, int colgroup, int c4, float4 v, float4 a, float4 g) const {
     const int64_t r0 = (int64_t)tile * bm;
     if (r0 + row >= M) return;
-    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-    v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+    if constexpr (ADD) { v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+    if constexpr (GATE) {
+      v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+    }
     *reinterpret_cast<float4*>(out + r0 * ldo + (unsigned)(row * ldo + colgroup * wgcols + 4 * c4)) = v;
   }
 };

@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            name = re.sub(r"\(.*", "", row["Kernel_Name"])[:60]
+            name = re.sub(r"\((?!anonymous).*", "", row["Kernel_Name"].replace("(anonymous namespace)::", ""))[:60]
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)
