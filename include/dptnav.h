@@ -217,6 +217,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 LayerNorm 1 of a TransformerDPRNN as ONE kernel when the sequences are <= 160 positions long (QKV and
  *                 the attention output stay on chip; the "qkv" / "att" workspace taps are then not written); 0 = the three
  *                 separate launches (always used by the training forward, which keeps qkv / att on the tape).
+ *   "fuse_ffn" (0/1, default 1): dptnav_forward leaves the FFN half (K6: Linear + residual + LayerNorm 2) of a path to the
+ *                 NEXT path's fused attention block, which produces its own input rows (attn_block.hip prologue): the
+ *                 tensor between two TransformerDPRNNs never goes through HBM.  Only where that block is the fused
+ *                 fp32 kernel; the stage entry points always run whole paths.
  *   "split_bf16" (0/1, default 0): OPT-IN experiment, never a parity claim -- the 16-sequence-tile recurrence of the
  *                 inference forward runs on bf16 MFMAs with every operand split into bf16 hi + lo (three products, fp32
  *                 accumulation: ~2^-17 relative error per product instead of 2^-24, ~5x less matrix time); lstm16s.hip.

@@ -50,12 +50,27 @@ DEV float half_sum(float v) {
   return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
-template <int NKB>
+// PRO = true: the block's input rows are not read from memory but PRODUCED here, as the second half of the PREVIOUS
+// TransformerDPRNN:  x = LayerNorm2(ReLU(h) W_f^T + b_f + y1_prev)  (dptn.py:50-51; K6 of dptnav.hip).  That GEMM is
+// token-wise and every token belongs to exactly one sequence of this launch, so each workgroup computes it for its own
+// rows (32-token blocks through LDS, wave w = output columns [32w, 32w+32) with its W_f slice in registers, LayerNorm in
+// row space) straight into the staged tile: x never goes to HBM.  y1 is updated IN PLACE (a workgroup reads y1_prev of
+// its tokens here and writes their y1 at the end; no other workgroup touches them).
+struct FfnPro {
+  const float* hc;      // [M][256] ReLU(h_fwd | h_bwd) of the previous path
+  const float* wf;      // ffn.1.weight [128][256]
+  const float* bf;
+  const float* g2;      // ln2 weight / bias of the previous path
+  const float* b2;
+};
+constexpr int LDHC = 256 + 4;
+
+template <int NKB, bool PRO>
 __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict__ x, const float* __restrict__ w_in,
                                                          const float* __restrict__ b_in, const float* __restrict__ w_o,
                                                          const float* __restrict__ b_o, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y1, SeqGeom g,
-                                                         float scale_log2e) {
+                                                         float scale_log2e, FfnPro pro) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                          // [NKB*32][LDX]  the sequence's token rows (rows >= len repeat the last one)
   float* P = smem + NKB * 32 * LDX;          // [4 heads][32 rows][LDP]  out-projection partial tiles of one query block
@@ -66,8 +81,79 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   const int64_t tok0 = seq_token_base(g, seq);
   const int tstride = seq_token_stride(g);
 
-  // ---- stage the token rows: coalesced 512-byte rows -> LDS (every wave reads all of them as MFMA fragments) -----
-  {
+  if constexpr (PRO) {
+    // ---- prologue: x rows = LN2(ReLU(h) W_f^T + b_f + y1_prev) of the previous path, block of 32 tokens at a time ----
+    float* Hs = P;                           // [32][LDHC]  ReLU(h) rows of the block (A operand)
+    float* Cs = P + 32 * LDHC;               // [32][LDP]   product tile on its way to row space
+    float wff[128];                          // W_f[32h + c][8m + 4hh + t]: this wave's 32 output columns, K = 256
+    {
+      const float* wr = pro.wf + (int64_t)(32 * h + c) * 256 + 4 * hh;
+#pragma unroll
+      for (int m = 0; m < 32; ++m) {
+        const float4 t = ldg4(wr + 8 * m);
+        wff[4 * m + 0] = t.x; wff[4 * m + 1] = t.y; wff[4 * m + 2] = t.z; wff[4 * m + 3] = t.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 128; ++i) asm volatile("" : "+a"(wff[i]));
+    }
+    const int pc4 = tid & 31, prs = tid >> 5;
+    const float4 bfc = ldg4(pro.bf + 4 * pc4), g2c = ldg4(pro.g2 + 4 * pc4), b2c = ldg4(pro.b2 + 4 * pc4);
+    auto tok_of = [&](int row) { return tok0 + (int64_t)(row < len ? row : len - 1) * tstride; };
+    float4 hst[8];                           // the block's 32 x 256 floats: 8 x 16 bytes per thread, one block ahead
+    auto fetch_h = [&](int rb) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + tid;
+        hst[i] = ldg4(pro.hc + tok_of(rb * 32 + (idx >> 6)) * 256 + 4 * (idx & 63));
+      }
+    };
+    fetch_h(0);
+    for (int rb = 0; rb < NKB; ++rb) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = i * 256 + tid;
+        *reinterpret_cast<float4*>(&Hs[(idx >> 6) * LDHC + 4 * (idx & 63)]) = hst[i];
+      }
+      __syncthreads();
+      if (rb + 1 < NKB) fetch_h(rb + 1);
+      float4 res[4];                         // residual rows y1_prev of this thread's four row-space slots
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) res[pass] = ldg4(y1 + tok_of(rb * 32 + pass * 8 + prs) * N + 4 * pc4);
+      f32x16 a0 = zero16(), a1 = zero16();
+      const float* ar = &Hs[c * LDHC + 4 * hh];
+#pragma unroll
+      for (int m0 = 0; m0 < 32; m0 += 8) {
+        float4 af[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) af[m] = *reinterpret_cast<const float4*>(ar + 8 * (m0 + m));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          a0 = mfma32(af[m].x, wff[4 * (m0 + m) + 0], a0);
+          a1 = mfma32(af[m].y, wff[4 * (m0 + m) + 1], a1);
+          a0 = mfma32(af[m].z, wff[4 * (m0 + m) + 2], a0);
+          a1 = mfma32(af[m].w, wff[4 * (m0 + m) + 3], a1);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cs[ROW32(r, hh) * LDP + 32 * h + c] = a0[r] + a1[r];
+      __syncthreads();
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = pass * 8 + prs;
+        const float4 cv = *reinterpret_cast<const float4*>(&Cs[row * LDP + 4 * pc4]);
+        float4 v;
+        v.x = cv.x + bfc.x + res[pass].x; v.y = cv.y + bfc.y + res[pass].y;
+        v.z = cv.z + bfc.z + res[pass].z; v.w = cv.w + bfc.w + res[pass].w;
+        const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
+        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+        const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
+        const float rstd = rsqrtf(var + 1e-5f);
+        *reinterpret_cast<float4*>(&Xs[(rb * 32 + row) * LDX + 4 * pc4]) =
+            make_float4(dx * rstd * g2c.x + b2c.x, dy * rstd * g2c.y + b2c.y, dz * rstd * g2c.z + b2c.z, dw * rstd * g2c.w + b2c.w);
+      }
+    }
+  } else {
+    // ---- stage the token rows: coalesced 512-byte rows -> LDS (every wave reads all of them as MFMA fragments) -----
     constexpr int NLD = NKB * 4;             // float4 per thread
     float4 st[NLD];
 #pragma unroll
@@ -575,31 +661,56 @@ __global__ __launch_bounds__(256) void attn_block_split_kernel(const float* __re
 size_t attn_block_lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * LDX + 4 * 32 * LDP); }
 
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
-                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split) {
+                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split, const AttnFfnPrologue* pro) {
   using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
-                        SeqGeom, float);
-  Kern kern;
+                        SeqGeom, float, FfnPro);
+  using KernS = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                         SeqGeom, float);
   const int nkb = (g.len + 31) / 32;
-  switch (nkb) {
-    case 1: kern = split ? attn_block_split_kernel<1> : attn_block_kernel<1>; break;
-    case 2: kern = split ? attn_block_split_kernel<2> : attn_block_kernel<2>; break;
-    case 3: kern = split ? attn_block_split_kernel<3> : attn_block_kernel<3>; break;
-    case 4: kern = split ? attn_block_split_kernel<4> : attn_block_kernel<4>; break;
-    case 5: kern = split ? attn_block_split_kernel<5> : attn_block_kernel<5>; break;
-    default: return (int)hipErrorInvalidValue;
-  }
-  static PerDeviceOnce ready_all[2][6];
-  PerDeviceOnce* ready = ready_all[split ? 1 : 0];
+  if (nkb < 1 || nkb > 5 || (split && pro)) return (int)hipErrorInvalidValue;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
   const int dev = current_hip_device();
-  // (the split variant keeps two bf16 images of the token rows: 2 x 272 bytes per row instead of 528)
-  const size_t lds = split ? sizeof(float) * 4 * 32 * LDP + sizeof(__bf16) * 2 * (size_t)nkb * 32 * LDXB : attn_block_lds_bytes(nkb);
+  if (split) {
+    KernS kern;
+    switch (nkb) {
+      case 1: kern = attn_block_split_kernel<1>; break;
+      case 2: kern = attn_block_split_kernel<2>; break;
+      case 3: kern = attn_block_split_kernel<3>; break;
+      case 4: kern = attn_block_split_kernel<4>; break;
+      default: kern = attn_block_split_kernel<5>; break;
+    }
+    // (the split variant keeps two bf16 images of the token rows: 2 x 272 bytes per row instead of 528)
+    const size_t lds = sizeof(float) * 4 * 32 * LDP + sizeof(__bf16) * 2 * (size_t)nkb * 32 * LDXB;
+    static PerDeviceOnce ready[6];
+    if (!ready[nkb].done(dev)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      ready[nkb].set(dev);
+    }
+    hipLaunchKernelGGL(kern, dim3(g.nseq), dim3(256), lds, static_cast<hipStream_t>(stream), x, w_in, b_in, w_o, b_o, gamma, beta,
+                       y1, g, scale_log2e);
+    return (int)hipGetLastError();
+  }
+  Kern kern;
+  const bool p = pro != nullptr;
+  switch (nkb) {
+    case 1: kern = p ? attn_block_kernel<1, true> : attn_block_kernel<1, false>; break;
+    case 2: kern = p ? attn_block_kernel<2, true> : attn_block_kernel<2, false>; break;
+    case 3: kern = p ? attn_block_kernel<3, true> : attn_block_kernel<3, false>; break;
+    case 4: kern = p ? attn_block_kernel<4, true> : attn_block_kernel<4, false>; break;
+    default: kern = p ? attn_block_kernel<5, true> : attn_block_kernel<5, false>; break;
+  }
+  const size_t lds = attn_block_lds_bytes(nkb);
+  static PerDeviceOnce ready_all[2][6];
+  PerDeviceOnce* ready = ready_all[p ? 1 : 0];
   if (!ready[nkb].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     ready[nkb].set(dev);
   }
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
-  hipLaunchKernelGGL(kern, dim3(g.nseq), dim3(256), lds, static_cast<hipStream_t>(stream), x, w_in, b_in, w_o, b_o, gamma, beta,
-                     y1, g, scale_log2e);
+  FfnPro fp{};
+  if (p) fp = FfnPro{pro->hc, pro->wf, pro->bf, pro->g2, pro->b2};
+  hipLaunchKernelGGL(kern, dim3(g.nseq), dim3(256), lds, static_cast<hipStream_t>(stream), x, w_in, b_in, w_o, b_o, gamma, beta, y1,
+                     g, scale_log2e, fp);
   return (int)hipGetLastError();
 }

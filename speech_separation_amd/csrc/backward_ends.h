@@ -27,7 +27,7 @@ struct EpiDecoderBwd {
   float wacc[4][8] = {};
   DEV float4 prefetch(int tile, int row, int c4) const {
     const int64_t r = (int64_t)tile * bm + row;
-    const int64_t e = r < 2 * BL ? (r % BL) : 0;
+    const int64_t e = r < BL ? r : (r < 2 * BL ? r - BL : 0);   // r mod BL for the two speakers' rows
     return *reinterpret_cast<const float4*>(E + e * (4 * GROUP) + 4 * c4);
   }
   DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) {
@@ -35,10 +35,10 @@ struct EpiDecoderBwd {
     if (r >= 2 * BL) return;
     const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
     const float q[4] = {v.x + b.x + x.x, v.y + b.y + x.y, v.z + b.z + x.z, v.w + b.w + x.w};
-    const int spk = (int)(r / BL);
-    const int64_t rem = r - (int64_t)spk * BL;
-    const int bb = (int)(rem / L);
-    const int t = (int)(rem - (int64_t)bb * L);
+    const int spk = r >= BL ? 1 : 0;
+    const int rem = (int)(r - (int64_t)spk * BL);
+    const int bb = fast_div(rem, L, 1.0f / (float)L);
+    const int t = rem - bb * L;
     const float* dy = (spk ? dy2 : dy1) + (int64_t)bb * T;
     float dq[4] = {0.f, 0.f, 0.f, 0.f};
     // (taps unrolled to the table width with a predicate: a runtime trip count made wacc[i][j] a dynamically indexed

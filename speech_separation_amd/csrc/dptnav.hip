@@ -78,6 +78,7 @@ struct dptnav_ctx {
   bool opt_lstm16 = true;
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
@@ -438,9 +439,18 @@ inline bool lstm_use16(const dptnav_ctx* c, const SeqGeom& geom, int ndir, int64
 }
 
 // ---- one TransformerDPRNN (dptn.py:36-52) ---------------------------------------------------------
+// chain: bit 0 -- the attention block PRODUCES its input rows itself, as the FFN half (K6) of the previous path (its hc /
+// y1 are still in the workspace; attn_block.hip prologue); bit 1 -- this path's K6 is left to the next path's block.
+constexpr int CHAIN_PRO = 1, CHAIN_SKIP_FFN = 2;
+template <int N>
+bool path_fusable(const dptnav_ctx* c, int path, int B, int S) {
+  const SeqGeom geom = make_geom(path, B, S, c->cfg.chunk_size);
+  return c->cfg.arch == 0 && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && c->cfg.num_heads == 4;
+}
+
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
-             const PathBufs* bufs = nullptr) {
+             const PathBufs* bufs = nullptr, int chain = 0) {
   float* ws = run.ws;
   const Plan& pl = run.pl;
   hipStream_t st = run.st;
@@ -462,8 +472,16 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const bool fused = dptn && !pb.train && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && g.num_heads == 4;
   if (fused) {
     ProfScope ps(c, CAT_ATTN, st);
-    const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16);
+    AttnFfnPrologue pro{};
+    if (chain & CHAIN_PRO) {
+      const PathWeights& pw = c->pw[2 * block + path - 1];
+      pro = AttnFfnPrologue{hc, pw.ffn_w, pw.ffn_b, pw.ln2_w, pw.ln2_b};
+    }
+    const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16,
+                                     (chain & CHAIN_PRO) ? &pro : nullptr);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention block: %s", hipGetErrorString((hipError_t)rc));
+  } else if (chain & CHAIN_PRO) {
+    return c->fail(DPTNAV_ERR_INVALID, "internal: FFN prologue requested for an unfused attention block");
   }
   // K1: qkv = x W_in^T + b_in                                  (nn.MultiheadAttention in-projection)
   if (dptn && !fused) {
@@ -544,6 +562,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     return DPTNAV_OK;
   }
   // K6: x_out = LN2(relu(h) W_f^T + b_f + y1)                    (dptn.py:50-51)
+  if (chain & CHAIN_SKIP_FFN) return DPTNAV_OK;   // done by the next path's attention block (its prologue)
   {
     EpiBiasResLN<GROUP> ep{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM};
     // (training keeps the raw h on the tape and applies ffn[0] = ReLU while loading)
@@ -1369,7 +1388,16 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
         }
         const float* xin = path == 0 ? X0(i) : X1(i);
         float* xout = path == 0 ? X1(i) : X0(i);
-        int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S)
+        // FFN (K6) of a path runs as the prologue of the NEXT path's attention block when that block is the fused kernel
+        // (fp32, N = 128, sequences <= 160): the block input x then never goes through HBM
+        int chain = 0;
+        if (big && h->opt_fuse_ffn && !h->opt_split_bf16) {
+          const int S_i = (int)pl[i].S;
+          const bool first = b == 0 && path == 0, last = b == g.num_blocks - 1 && path == 1;
+          if (!first && path_fusable<128>(h, path, Bs[i], S_i)) chain |= CHAIN_PRO;
+          if (!last && path_fusable<128>(h, 1 - path, Bs[i], S_i)) chain |= CHAIN_SKIP_FFN;
+        }
+        int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S, nullptr, chain)
                      : run_path<64>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S);
         if (rc) return rc;
         prev = i;
@@ -1812,6 +1840,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
+  else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;

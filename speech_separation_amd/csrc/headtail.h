@@ -110,19 +110,34 @@ __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restri
 // post-processing 1x1 conv (dptn_wav.py:31-33,59); the epilogue adds bias + fused latent E (skip,
 // dptn_wav.py:188) and projects on the k decoder taps (ConvTranspose1d weights, dptn_wav.py:167-169).
 // ------------------------------------------------------------------------------------------------
+// Exact floor(n / d) for n >= 0, d >= 1 without an integer division where it matters (a 64-bit division costs ~100
+// instructions, and the loaders / epilogues below ran three per 16-byte load: 0.13 MFMA-busy): below 2^23 the float
+// conversion of n is exact and the estimate n * (1/d) is within +-1 of the quotient, fixed by one correction step each
+// way (checked exhaustively against // on the CPU for the divisors in use); larger n take the hardware path.
+DEV int fast_div(int n, int d, float inv_d) {
+  if (n >= (1 << 23)) return n / d;
+  int q = (int)((float)n * inv_d);
+  const int r = n - q * d;
+  q += r >= d ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+
 struct ALoadOla {
   const float* Z;  // (M, 2N) separated tokens
   int N, B, L, S, K, P, left, ola, bm;
   DEV float4 load4(int tile, int row, int k4) const {
-    const int64_t r = (int64_t)tile * bm + row;
+    // rows r = (spk*B + b)*L + frame, all below 2^31 (host-checked plan limit): 32-bit arithmetic, no divisions
+    const int r = tile * bm + row;
+    const int BL = B * L;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r >= (int64_t)2 * B * L) return acc;
-    const int spk = (int)(r / ((int64_t)B * L));
-    const int64_t rem = r - (int64_t)spk * B * L;
-    const int b = (int)(rem / L);
-    const int t = (int)(rem - (int64_t)b * L) - left;
+    if (r >= 2 * BL) return acc;
+    const int spk = r >= BL ? 1 : 0;
+    const int rem = r - spk * BL;
+    const int b = fast_div(rem, L, 1.0f / (float)L);
+    const int t = rem - b * L - left;
     if (t < 0 || t >= ola) return acc;
-    int s_hi = t / P;
+    int s_hi = fast_div(t, P, 1.0f / (float)P);
     if (s_hi > S - 1) s_hi = S - 1;
     for (int s = s_hi; s >= 0 && t - P * s < K; --s) {
       const float4 z = *reinterpret_cast<const float4*>(Z + (((int64_t)b * S + s) * K + (t - P * s)) * (2 * N) +
@@ -145,7 +160,7 @@ struct EpiSkipDecoderTaps {
   int kenc, bm;
   DEV float4 prefetch(int tile, int row, int c4) const {   // fused latent row of this frame (skip connection)
     const int64_t r = (int64_t)tile * bm + row;
-    const int64_t e = r < 2 * BL ? (r % BL) : 0;
+    const int64_t e = r < BL ? r : (r < 2 * BL ? r - BL : 0);   // r mod BL for the two speakers' rows
     return *reinterpret_cast<const float4*>(E + e * (4 * GROUP) + 4 * c4);
   }
   DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x) const {
