@@ -389,6 +389,21 @@ def main():
         cu_share = min(1.0, wgs / n_cus)
         if iso is not None:
             iso["kernel"] = "lstm_recurrence_kernel"
+        # the other large kernel class, same convention (algorithmic FLOPs of one launch / its mean time as run): the
+        # fused attention block, which since round 2 also carries the FFN half of the previous path
+        other = None
+        if args.config == "dptn_av" and prof["attention"][1]:
+            a_ms, a_n = prof["attention"]
+            N_ = cfg.num_features
+            per_tok = 2 * N_ * 3 * N_ + 2 * N_ * N_ + 4 * ((K + S) / 2.0) * N_                  # QKV + out-proj + scores / PV
+            fused_ffn = prof["ffn_ln_gemm"][1] < a_n                                             # K6 rides in the block
+            per_tok += (2 * 2 * H * N_) * (1.0 - prof["ffn_ln_gemm"][1] / a_n) if fused_ffn else 0.0
+            a_flops = float(M) * (2 * cfg.num_blocks) * per_tok / (a_n / psteps)
+            a_tf = a_flops / (a_ms / a_n * 1e-3) / 1e12
+            other = {"kernel": "attn_block_kernel (in-proj + attention + out-proj + LN1" + (" + FFN/LN2 of the previous path)" if fused_ffn else ")"),
+                     "launch_ms": round(a_ms / a_n, 4), "launches_per_step": a_n / psteps, "achieved": round(a_tf, 3),
+                     "frac": round(a_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                     "note": "as run, beside the other sub-batch's recurrence (146 of 256 CUs)"}
         value = env.world * B * args.steps / elapsed
         # HBM traffic: from the committed PMC table (same configuration, batch and kernel only), never extrapolated
         tab = pmc_table(args.config)
@@ -420,7 +435,7 @@ def main():
                          "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
                          "cus_occupied": round(wgs, 1), "frac_of_occupied_cus": round(achieved / (PEAK_F32_MFMA_TFLOPS * cu_share), 4),
                          "launches_per_step": launches_per_step,
-                         "isolated": iso,
+                         "isolated": iso, "second_kernel": other,
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},
