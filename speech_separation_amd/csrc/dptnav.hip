@@ -514,6 +514,9 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     } else if (use16) {
       EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
       rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+    } else if (split) {
+      EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
+      rc = launch_gemm<N, 4, 1, 4, false, true>(c, run, CAT_LSTM_PRE, "lstm-pre gemm (split)", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
     } else {
       EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
       rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
@@ -537,6 +540,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     const int rc = lstm16_launch(variant, c->cfg.arch == 0 && !pb.train, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
                                  w.ndir * LSTM_H, (int)M, geom, stamps, pb.gates, pb.cst);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16: %s", hipGetErrorString((hipError_t)rc));
+  } else if (split) {
+    ProfScope ps(c, CAT_LSTM, st);
+    const int rc = lstm32s_launch(c->cfg.arch == 0, geom.nst, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm32s: %s", hipGetErrorString((hipError_t)rc));
   } else {
     // diagnostic stamps land behind the dump rows of hc (see make_plan)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ws + pl.stamps);
@@ -552,7 +559,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K6 (DPRNN): x_out = LayerNorm(h W_fc^T + b_fc) + x_in       (dprnn.py:41-45, 83-87)
   if (!dptn) {
     EpiBiasLNRes<GROUP> ep{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM};
-    if (w.ndir == 2) {
+    if (w.ndir == 2 && split) {
+      ALoadDense al{hc, M, 2 * LSTM_H, BM};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC, false, true>(c, run, CAT_FFN, "fc gemm (split)", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else {

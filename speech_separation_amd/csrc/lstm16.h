@@ -43,3 +43,6 @@ int lstm16_launch(int variant, bool relu, int nst16, int ndir, void* stream, con
 // operand split into bf16 hi + lo (3 products, fp32 accumulation); same PRE16 input, same fp32 output.  Inference only.
 int lstm16s_launch(bool relu, int nst16, int ndir, void* stream, const float* pre, const float* whh_f, const float* whh_b,
                    float* hc, int ldh, int dump_row, const SeqGeom& g);
+// ... and of the 32-sequence-tile recurrence (same file; PRE layout of lstm.h).
+int lstm32s_launch(bool relu, int nst, int ndir, void* stream, const float* pre, const float* whh_f, const float* whh_b, float* hc,
+                   int ldh, int dump_row, const SeqGeom& g);

@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include "lstm.h"
 #include "lstm16.h"
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
     float4 hs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
+    // (without this pin the allocator tries the full AGPR half for these load results and spills them)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(hs[j].x), "+v"(hs[j].y), "+v"(hs[j].z), "+v"(hs[j].w));
     // branch-free: beyond the last step the requests re-read the last tile into a set nobody uses any more
     const float* pnext = tile_of(step + 2);
     const unsigned adv = step > 0 ? sstep : 0u;
@@ -203,6 +207,184 @@ __global__ __launch_bounds__(256) void lstm16s_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 32-sequence tiles (whole-batch launches, DPRNN / long utterances: config 5), same split-precision scheme on
+// v_mfma_f32_32x32x16_bf16.  Structure of lstm.hip: wave w = hidden units [32w, 32w+32) of all four gates (4 accumulator
+// tiles, rows = sequences), W_hh as 4 x 8 hi / lo B fragments in the 256 AGPRs (lane (c,hh): W[gate*128 + 32w + c]
+// [16m + 8hh + j]), pre-activations (fp32, PRE layout of lstm.h) by LDS-DMA one step ahead, h_t through LDS as fp32 rows
+// (for HBM) + bf16 hi / lo images (A fragments: ds_read_b128 = 8 consecutive k of one sequence row).
+constexpr int LDB32 = LSTM_H + 8;
+constexpr int HB32_ELEMS = 2 * 32 * LDB32;
+constexpr size_t LDS32_BYTES = LSTM_LDS_BYTES + sizeof(__bf16) * 2 * HB32_ELEMS;
+
+DEV f32x16 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 c) {
+  c = mfma32_bf16(ah, bh, c);
+  c = mfma32_bf16(ah, bl, c);
+  return mfma32_bf16(al, bh, c);
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void lstm32s_kernel(const float* __restrict__ pre, const float* __restrict__ whh_f,
+                                                      const float* __restrict__ whh_b, float* __restrict__ hc, int ldh,
+                                                      int dump_row, SeqGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                      // fp32 [2][32][LSTM_LDH]
+  float* Ps = smem + LSTM_HS_FLOATS;     // [4 waves][16 pieces][64 lanes][4]
+  __bf16* Hhi = reinterpret_cast<__bf16*>(smem + LSTM_HS_FLOATS + LSTM_PRE_FLOATS);   // [2][32][LDB32]
+  __bf16* Hlo = Hhi + HB32_ELEMS;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  const int st = blockIdx.x, d = blockIdx.y;
+  const float* whh = d ? whh_b : whh_f;
+
+  bf16x8 whi[4][8], wlo[4][8];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const float* wrow = whh + (int64_t)(gi * LSTM_H + 32 * w + c) * LSTM_H + 8 * hh;
+    const float gs = lstm_gate_scale(gi);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float4 v0 = *reinterpret_cast<const float4*>(wrow + 16 * m), v1 = *reinterpret_cast<const float4*>(wrow + 16 * m + 4);
+      const float x[8] = {v0.x * gs, v0.y * gs, v0.z * gs, v0.w * gs, v1.x * gs, v1.y * gs, v1.z * gs, v1.w * gs};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 hi = (__bf16)x[j];
+        whi[gi][m][j] = hi;
+        wlo[gi][m][j] = (__bf16)(x[j] - (float)hi);
+      }
+    }
+  }
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" : "+a"(whi[gi][m]), "+a"(wlo[gi][m]));
+
+  const int t0 = d ? g.len - 1 : 0;
+  const int tdir = d ? -1 : 1;
+  const int tstride = seq_token_stride(g);
+  const int srow = 8 * w + hh, scol = 4 * c;
+  const int64_t sstep = (int64_t)tdir * tstride * ldh;
+  float* sp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = st * 32 + srow + 2 * j;
+    const int64_t tokb = q < g.nseq ? seq_token_base(g, q) : (int64_t)dump_row;
+    sp[j] = hc + (tokb + (int64_t)t0 * tstride) * ldh + d * LSTM_H + scol;
+  }
+  for (int i = tid; i < 32 * LSTM_LDH; i += 256) Hs[i] = 0.f;
+  for (int i = tid; i < 32 * LDB32; i += 256) { Hhi[i] = (__bf16)0.f; Hlo[i] = (__bf16)0.f; }
+  f32x16 cst = zero16();
+
+  const float* pre_lane = pre + pre_tile_offset(d, st, 0, g.nst, g.len) + (int64_t)w * 1024 + lane * 4;
+  float* ps_wave = Ps + w * (16 * 256);
+  auto issue_pre_piece = [&](const float* p, int piece) {   // piece = gi*4 + q (compile-time after unrolling)
+    const int gi = piece >> 2;
+    switch (piece & 3) {
+      case 0: glds16_off<0>(p + gi * 4096, ps_wave + gi * 1024); break;
+      case 1: glds16_off<1024>(p + gi * 4096, ps_wave + gi * 1024); break;
+      case 2: glds16_off<2048>(p + gi * 4096, ps_wave + gi * 1024); break;
+      default: glds16_off<3072>(p + gi * 4096, ps_wave + gi * 1024); break;
+    }
+  };
+#pragma unroll
+  for (int piece = 0; piece < 16; ++piece) issue_pre_piece(pre_lane + (int64_t)t0 * (512 * 32), piece);
+  __syncthreads();
+
+  f32x16 acc[4];
+  auto preload_acc = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(ps_wave + (gi * 4 + q) * 256 + lane * 4);
+        acc[gi][4 * q + 0] = v.x;
+        acc[gi][4 * q + 1] = v.y;
+        acc[gi][4 * q + 2] = v.z;
+        acc[gi][4 * q + 3] = v.w;
+      }
+  };
+  preload_acc();
+
+  for (int step = 0; step < g.len; ++step) {
+    const int t = t0 + tdir * step;
+    const int cur = step & 1, nxt = cur ^ 1;
+    const float* hcur = Hs + cur * 32 * LSTM_LDH;
+    float* hnext = Hs + nxt * 32 * LSTM_LDH;
+    __bf16* hinext = Hhi + nxt * 32 * LDB32;
+    __bf16* lonext = Hlo + nxt * 32 * LDB32;
+    bf16x8 ahi[8], alo[8];
+    {
+      const __bf16* ar = Hhi + cur * 32 * LDB32 + c * LDB32 + 8 * hh;
+      const __bf16* br = Hlo + cur * 32 * LDB32 + c * LDB32 + 8 * hh;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        ahi[m] = *reinterpret_cast<const bf16x8*>(ar + 16 * m);
+        alo[m] = *reinterpret_cast<const bf16x8*>(br + 16 * m);
+      }
+    }
+    float4 hs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * LSTM_LDH + scol);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) asm volatile("" : "+v"(acc[gi]));
+    // (without this pin the allocator tries the full AGPR half for these load results and spills them)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(hs[j].x), "+v"(hs[j].y), "+v"(hs[j].z), "+v"(hs[j].w));
+    const float* pnext = pre_lane + (int64_t)(step + 1 < g.len ? t + tdir : t) * (512 * 32);
+    const int64_t adv = step > 0 ? sstep : 0;
+    if (RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hs[j] = make_float4(relu1(hs[j].x), relu1(hs[j].y), relu1(hs[j].z), relu1(hs[j].w));
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        acc[gi] = mfma3(ahi[m], alo[m], whi[gi][m], wlo[gi][m], acc[gi]);
+        // one memory instruction per MFMA group: the four row stores of h_{t-1}, then the 16 LDS-DMA requests
+        const int slot = 4 * m + gi;
+        if (slot < 4) {
+          *reinterpret_cast<float4*>(sp[slot]) = hs[slot];
+          sp[slot] += adv;
+        } else if (slot < 20) {
+          issue_pre_piece(pnext, slot - 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const LstmCell2 u = lstm_cell2((f32x2){acc[0][r], acc[0][r + 1]}, (f32x2){acc[1][r], acc[1][r + 1]},
+                                     (f32x2){acc[2][r], acc[2][r + 1]}, (f32x2){acc[3][r], acc[3][r + 1]},
+                                     (f32x2){cst[r], cst[r + 1]});
+      cst[r] = u.c.x;
+      cst[r + 1] = u.c.y;
+      const float hv[2] = {u.h.x, u.h.y};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int row = ROW32(r + e, hh), col = 32 * w + c;
+        const __bf16 hi = (__bf16)hv[e];
+        hnext[row * LSTM_LDH + col] = hv[e];
+        hinext[row * LDB32 + col] = hi;
+        lonext[row * LDB32 + col] = (__bf16)(hv[e] - (float)hi);
+      }
+    }
+    if (step + 1 < g.len) preload_acc();
+    __syncthreads();
+  }
+  {
+    const float* hfin = Hs + (g.len & 1) * 32 * LSTM_LDH;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 v = *reinterpret_cast<const float4*>(hfin + (srow + 2 * j) * LSTM_LDH + scol);
+      if (RELU) v = make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w));
+      *reinterpret_cast<float4*>(sp[j]) = v;
+    }
+  }
+}
+
 constexpr size_t LDS_BYTES = sizeof(float) * L16_HS_FLOATS + sizeof(__bf16) * 2 * HB_ELEMS;
 
 }  // namespace
@@ -220,5 +402,21 @@ int lstm16s_launch(bool relu, int nst16, int ndir, void* stream, const float* pr
   }
   hipLaunchKernelGGL(kern, dim3(nst16, ndir), dim3(256), LDS_BYTES, static_cast<hipStream_t>(stream), pre, whh_f, whh_b, hc, ldh,
                      dump_row, g, nst16);
+  return (int)hipGetLastError();
+}
+
+int lstm32s_launch(bool relu, int nst, int ndir, void* stream, const float* pre, const float* whh_f, const float* whh_b, float* hc,
+                   int ldh, int dump_row, const SeqGeom& g) {
+  auto kern = relu ? lstm32s_kernel<true> : lstm32s_kernel<false>;
+  static PerDeviceOnce ready[2];
+  const int dev = current_hip_device();
+  if (!ready[relu].done(dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS32_BYTES);
+    if (e != hipSuccess) return (int)e;
+    ready[relu].set(dev);
+  }
+  hipLaunchKernelGGL(kern, dim3(nst, ndir), dim3(256), LDS32_BYTES, static_cast<hipStream_t>(stream), pre, whh_f, whh_b, hc, ldh,
+                     dump_row, g);
   return (int)hipGetLastError();
 }
