@@ -202,6 +202,106 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   }
 }
 
+// Two weight gradients that share their Y operand in ONE pass over Y:  dWa = sum Y^T Xa,  dWb = sum Y^T Xb  (the LSTM's
+// W_ih and W_hh gradients: Y = dP, Xa = the layer input, Xb = h_{t-1}).  The Y tile is staged and its fragments are
+// read once for 2 x CB MFMAs each; 2 x RB x CB accumulator tiles per wave (256 registers for <256,128>: they live in
+// the AGPR half, one workgroup per CU as before).  slab[blockIdx.x][2][NN][KK].
+template <int NN, int KK, class YLoad, class XLoadA, class XLoadB>
+__global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __restrict__ queue, YLoad yl, XLoadA xa, XLoadB xb,
+                                                      float* __restrict__ slab) {
+  using Sh = WgradShape<NN, KK>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_next = reinterpret_cast<int*>(smem);
+  float* Ys = smem + 4;
+  float* Xas = Ys + 32 * Sh::LDY;
+  float* Xbs = Xas + 32 * Sh::LDX;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  f32x16 acca[Sh::RB][Sh::CB], accb[Sh::RB][Sh::CB];
+#pragma unroll
+  for (int a = 0; a < Sh::RB; ++a)
+#pragma unroll
+    for (int b = 0; b < Sh::CB; ++b) {
+      acca[a][b] = zero16();
+      accb[a][b] = zero16();
+    }
+  constexpr int Y4 = NN / 4, X4 = KK / 4;
+  constexpr int NY = (32 * Y4) / 256, NX = (32 * X4) / 256;
+  float4 py[NY], pxa[NX], pxb[NX];
+  int ticket_ahead = 0;
+  if (tid == 0) {
+    s_next[0] = (int)atomicAdd(queue, 1u);
+    ticket_ahead = (int)atomicAdd(queue, 1u);
+  }
+  __syncthreads();
+  int tile = s_next[0];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) py[i] = yl.load4(t, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      pxa[i] = xa.load4(t, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+      pxb[i] = xb.load4(t, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+    }
+  };
+  if (tile < ntiles) fetch(tile);
+  int par = 0;
+  while (tile < ntiles) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * Sh::LDY + 4 * (idx % Y4)]) = py[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Xas[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = pxa[i];
+      *reinterpret_cast<float4*>(&Xbs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = pxb[i];
+    }
+    if (tid == 0) s_next[par ^ 1] = ticket_ahead;
+    __syncthreads();
+    const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
+    if (next < ntiles) fetch(next);
+    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;
+      const float* xarow = Xas + (2 * s + hh) * Sh::LDX + c;
+      const float* xbrow = Xbs + (2 * s + hh) * Sh::LDX + c;
+      float a[Sh::RB], ba[Sh::CB], bb[Sh::CB];
+#pragma unroll
+      for (int i = 0; i < Sh::RB; ++i) a[i] = yrow[(w + 4 * i) * 32];
+#pragma unroll
+      for (int j = 0; j < Sh::CB; ++j) {
+        ba[j] = xarow[j * 32];
+        bb[j] = xbrow[j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < Sh::RB; ++i)
+#pragma unroll
+        for (int j = 0; j < Sh::CB; ++j) {
+          acca[i][j] = mfma32(a[i], ba[j], acca[i][j]);
+          accb[i][j] = mfma32(a[i], bb[j], accb[i][j]);
+        }
+    }
+    tile = next;
+    par ^= 1;
+  }
+  float* outa = slab + (size_t)blockIdx.x * (2 * NN * KK);
+  float* outb = outa + NN * KK;
+#pragma unroll
+  for (int i = 0; i < Sh::RB; ++i)
+#pragma unroll
+    for (int j = 0; j < Sh::CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const size_t o = (size_t)((w + 4 * i) * 32 + ROW32(r, hh)) * KK + j * 32 + c;
+        outa[o] = acca[i][j][r];
+        outb[o] = accb[i][j][r];
+      }
+}
+
 // column sums over the rows of Y[M][ld] (columns [col0, col0+C)): slab[blockIdx.x][C]
 template <int C>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int64_t M, int ld, int col0,
@@ -253,6 +353,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += red[j][e];
     out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// same, slabs `stride` floats apart (two interleaved partial tiles per workgroup: wgrad2_kernel), overwrite only
+__global__ __launch_bounds__(256) void slab_reduce_strided_kernel(const float* __restrict__ slab, int nslabs, int64_t count,
+                                                                   int64_t stride, float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int k = sl;
+    for (; k + 24 < nslabs; k += 32) {
+      s0 += slab[(size_t)k * stride + i];
+      s1 += slab[(size_t)(k + 8) * stride + i];
+      s2 += slab[(size_t)(k + 16) * stride + i];
+      s3 += slab[(size_t)(k + 24) * stride + i];
+    }
+    for (; k < nslabs; k += 8) s0 += slab[(size_t)k * stride + i];
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][e];
+    out[i] = s;
   }
 }
 

@@ -78,6 +78,7 @@ struct dptnav_ctx {
   bool opt_lstm16 = true;
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_wgrad2 = true;           // training: LSTM W_ih / W_hh gradients in one pass over dP (wgrad2_kernel)
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
@@ -775,6 +776,33 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
   return DPTNAV_OK;
 }
 
+// two gradients sharing the Y operand in one pass (wgrad2_kernel): gradA = sum Y^T Xa, gradB = sum Y^T Xb
+template <int NN, int KK, class YL, class XA, class XB>
+int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XA& xa, const XB& xb,
+                  float* gradA, float* gradB) {
+  const size_t lds = sizeof(float) * (4 + 32 * (size_t)(WgradShape<NN, KK>::LDY + 2 * WgradShape<NN, KK>::LDX));
+  const int grid = cap_grid(ntiles, br.pl.slab_wgs);
+  float* slab = br.ws + br.pl.slab;            // [grid][2][NN][KK]: BWD_SLAB_WGS x 512 x 128 floats hold <256,128> exactly
+  static_assert(2 * NN * KK <= 512 * 128, "slab size");
+  auto kern = wgrad2_kernel<NN, KK, YL, XA, XB>;
+  static PerDeviceOnce ready;
+  if (!ready.done(c->device_id)) {
+    if (int rc = set_lds(c, kern, lds, what)) return rc;
+    ready.set(c->device_id);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xa, xb, slab);
+  LAUNCH_CHECK(c, what);
+  const int64_t count = (int64_t)NN * KK;
+  // slab_reduce walks slabs with stride `count`: here a workgroup's two partial tiles are 2*count apart -> view the
+  // region as 2*grid slabs and reduce the even / odd ones (nslabs = grid, stride 2*count) through the `stride` form
+  hipLaunchKernelGGL(slab_reduce_strided_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count,
+                     2 * count, gradA);
+  hipLaunchKernelGGL(slab_reduce_strided_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab + count, grid, count,
+                     2 * count, gradB);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
 // grad[C] = column sums of Y[:, col0:col0+C]   (second destination optional: b_ih and b_hh share their gradient)
 template <int C>
 int launch_colsum(dptnav_ctx* c, BwdRun& br, const char* what, const float* Y, int64_t M, int ld, int col0, float* grad,
@@ -873,8 +901,15 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     ALoadSeqShift hl{hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom};
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
       ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
-      if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
-      if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
+      if (c->opt_wgrad2) {   // W_ih and W_hh gradients in ONE pass over dP
+        static_assert(N == LSTM_H, "wgrad2 pairs two operands of equal width");
+        if (int rc = launch_wgrad2<256, N>(c, br, "d w_ih + d w_hh", ntiles, yl, xl, hl, G(wih.c_str()) + half * 256 * N,
+                                           G(whh.c_str()) + half * 256 * LSTM_H))
+          return rc;
+      } else {
+        if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
+        if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
+      }
     }
   }
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
@@ -1851,6 +1886,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
+  else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
