@@ -221,6 +221,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 NEXT path's fused attention block, which produces its own input rows (attn_block.hip prologue): the
  *                 tensor between two TransformerDPRNNs never goes through HBM.  Only where that block is the fused
  *                 fp32 kernel; the stage entry points always run whole paths.
+ *   "fold_tail" (0/1, default 1): inference computes the decoder tap products as ONE contraction per frame,
+ *                 [OLA(mask) | encoded] . [W_dec^T W_post | W_dec^T] + W_dec^T b_post (folded from the current weights on
+ *                 every call), instead of the post-processing GEMM with a k-reduction epilogue.
+ *   "wgrad2" (0/1, default 1): training computes the W_ih and W_hh gradients of an LSTM in one pass over dP.
  *   "split_bf16" (0/1, default 0): OPT-IN experiment, never a parity claim -- the 16-sequence-tile recurrence of the
  *                 inference forward runs on bf16 MFMAs with every operand split into bf16 hi + lo (three products, fp32
  *                 accumulation: ~2^-17 relative error per product instead of 2^-24, ~5x less matrix time); lstm16s.hip.

@@ -37,7 +37,7 @@ constexpr int QUEUE_SLOTS = 1024;
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -78,6 +78,7 @@ struct dptnav_ctx {
   bool opt_lstm16 = true;
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
   bool opt_wgrad2 = true;           // training: LSTM W_ih / W_hh gradients in one pass over dP (wgrad2_kernel)
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
@@ -320,6 +321,7 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->hc_n = (size_t)p->M * 2 * H;
   p->hc = take(p->hc_n + (size_t)p->S * g.chunk_size * 2 * H);   // + dump rows for padded sequences
   p->stamps = take((size_t)2 * 2 * (nst_a > nst_e ? nst_a : nst_e) * 4 * 4 * 2);   // u64 [dir][tile][wave][4]
+  p->wfold = take((size_t)8 * 2 * N + 8);   // folded decoder weights [G | W_dec^T | bd] (run_tail)
   p->total = o;
   return DPTNAV_OK;
 }
@@ -645,7 +647,17 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
   // T2: overlap-add gather -> post-processing conv -> + E -> decoder tap products
   const int ola = (int)((pl.S - 1) * g.step_size + g.chunk_size);
   const int left = (int)((pl.L - ola) / 2);
-  {
+  if (Zbuf == nullptr && c->opt_fold_tail) {
+    // inference: the three linear steps folded into one contraction of length 2N per frame (headtail.h)
+    float* Wf = ws + pl.wfold;
+    ProfScope ps(c, CAT_POST, st);
+    hipLaunchKernelGGL(fold_decoder_kernel<N>, dim3(8), dim3(N), 0, st, c->w("dprnn.postprocessing.0.weight"),
+                       c->w("dprnn.postprocessing.0.bias"), c->w("decoder.weight"), g.kernel_size_enc, Wf);
+    const int64_t rows = (int64_t)2 * B * pl.L;
+    hipLaunchKernelGGL(taps_fold_kernel<N>, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, Z, E, Wf, D, B, (int)pl.L,
+                       (int)pl.S, g.chunk_size, g.step_size, left, ola);
+    LAUNCH_CHECK(c, "folded post-processing / decoder taps");
+  } else {
     const int64_t rows = (int64_t)2 * B * pl.L;
     ALoadOla al{Z, N, B, (int)pl.L, (int)pl.S, g.chunk_size, g.step_size, left, ola, BM};
     EpiSkipDecoderTaps<GROUP> ep{D, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"),
@@ -1887,6 +1899,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
+  else if (k == "fold_tail") h->opt_fold_tail = value != 0;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;

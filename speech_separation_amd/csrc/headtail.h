@@ -179,6 +179,91 @@ struct EpiSkipDecoderTaps {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// tail stage 2, FOLDED form (inference): the decoder only ever sees q W_dec with q = u W_post^T + b_post + E, so the
+// 1x1 post-processing conv, the skip and the k tap projections collapse into ONE contraction of length 2N per frame:
+//     D[r][j] = [u_r | E_r] . [G_j | W_dec[:, j]] + bd_j,   G = W_dec^T W_post (k x N),  bd = W_dec^T b_post
+// (dptn_wav.py:59,188-190: ConvTranspose1d(postprocessing(mask) + encoded)).  The GEMM-engine form above spends its time
+// in an epilogue of k 32-lane reductions per row (0.13 MFMA-busy); this form is bandwidth-bound: 1.5 kB in, 32 B out
+// per frame.  fold_decoder_kernel builds [G | W_dec^T | bd] from the CURRENT weights on every call (they may have
+// been updated), 8 x 2N + 8 floats.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(N) void fold_decoder_kernel(const float* __restrict__ wpost, const float* __restrict__ bpost,
+                                                          const float* __restrict__ wdec, int kenc, float* __restrict__ Wf) {
+  // grid = 8 taps, thread = input channel k.  Wf[j][0:N] = G_j, Wf[j][N:2N] = W_dec[:, j], Wf[8][j] = bd_j  (rows j >= kenc: 0)
+  __shared__ float red[N];
+  const int j = blockIdx.x, k = threadIdx.x;
+  float g = 0.f;
+  if (j < kenc)
+    for (int c = 0; c < N; ++c) g = fmaf(wdec[c * kenc + j], wpost[c * N + k], g);   // wpost row c: coalesced over k
+  Wf[j * 2 * N + k] = g;
+  Wf[j * 2 * N + N + k] = j < kenc ? wdec[k * kenc + j] : 0.f;
+  red[k] = j < kenc ? bpost[k] * wdec[k * kenc + j] : 0.f;
+  __syncthreads();
+  if (k == 0) {
+    float b = 0.f;
+    for (int c = 0; c < N; ++c) b += red[c];
+    Wf[8 * 2 * N + j] = b;
+  }
+}
+
+// One workgroup = 32 frames (rows r of the (2, B, L) frame list); thread = (frame f = tid / 8, tap j = tid % 8).
+template <int N>
+__global__ __launch_bounds__(256) void taps_fold_kernel(const float* __restrict__ Z, const float* __restrict__ E,
+                                                         const float* __restrict__ Wf, float* __restrict__ D, int B, int L,
+                                                         int S, int K, int P, int left, int ola) {
+  constexpr int LDU = 2 * N + 4;            // rows 4 banks apart: the wave's 8 frame rows / 8 tap rows read conflict-free
+  __shared__ __attribute__((aligned(16))) float Us[32 * LDU];
+  __shared__ __attribute__((aligned(16))) float Ws[8 * LDU];
+  const int tid = threadIdx.x;
+  const int BL = B * L, rows = 2 * BL;
+  const int r0 = blockIdx.x * 32;
+  for (int i = tid; i < 8 * (2 * N / 4); i += 256) {
+    const int j = i / (2 * N / 4), k4 = i - j * (2 * N / 4);
+    *reinterpret_cast<float4*>(&Ws[j * LDU + 4 * k4]) = *reinterpret_cast<const float4*>(Wf + j * 2 * N + 4 * k4);
+  }
+  const float invL = 1.0f / (float)L, invP = 1.0f / (float)P;
+  constexpr int K4 = 2 * N / 4;             // float4 per staged row: [u (N) | E (N)]
+#pragma unroll
+  for (int i = 0; i < (32 * K4) / 256; ++i) {
+    const int idx = i * 256 + tid;
+    const int row = idx / K4, k4 = idx - row * K4;
+    const int r = r0 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const int spk = r >= BL ? 1 : 0;
+      const int rem = r - spk * BL;
+      if (k4 >= N / 4) {                    // fused latent row (skip connection)
+        v = *reinterpret_cast<const float4*>(E + (int64_t)rem * N + 4 * (k4 - N / 4));
+      } else {                              // overlap-add gather of the speaker's mask rows (ALoadOla)
+        const int b = fast_div(rem, L, invL);
+        const int t = rem - b * L - left;
+        if (t >= 0 && t < ola) {
+          int s_hi = fast_div(t, P, invP);
+          if (s_hi > S - 1) s_hi = S - 1;
+          for (int s = s_hi; s >= 0 && t - P * s < K; --s) {
+            const float4 z = *reinterpret_cast<const float4*>(Z + (((int64_t)b * S + s) * K + (t - P * s)) * (2 * N) + spk * N + 4 * k4);
+            v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w;
+          }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(&Us[row * LDU + 4 * k4]) = v;
+  }
+  __syncthreads();
+  const int f = tid >> 3, j = tid & 7;
+  const float* u = &Us[f * LDU];
+  const float* w = &Ws[j * LDU];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+  for (int k4 = 0; k4 < K4; ++k4) {
+    const float4 x = *reinterpret_cast<const float4*>(u + 4 * k4), y = *reinterpret_cast<const float4*>(w + 4 * k4);
+    a0 = fmaf(x.x, y.x, a0); a1 = fmaf(x.y, y.y, a1); a2 = fmaf(x.z, y.z, a2); a3 = fmaf(x.w, y.w, a3);
+  }
+  if (r0 + f < rows) D[(int64_t)(r0 + f) * 8 + j] = ((a0 + a1) + (a2 + a3)) + Wf[8 * 2 * N + j];
+}
+
 // tail stage 3: y[n] = sum over taps j == n (mod stride) of D[(n-j)/stride][j]; zero pad to T
 //   (ConvTranspose1d scatter turned into a gather; dptn_wav.py:188-192)
 __global__ __launch_bounds__(256) void decoder_gather_kernel(const float* __restrict__ D, float* __restrict__ s1,
