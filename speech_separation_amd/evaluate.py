@@ -62,6 +62,7 @@ def run_inference(model: Callable[..., Mapping[str, torch.Tensor]], entries: Lis
     batcher = PinnedBatcher(dev)
     writer = PredictionWriter(dev) if save_dir is not None else None
     sums = [0.0] * len(metrics)
+    met_means = []        # per batch: the metrics' device-side means (read once, after the loop: no stall per batch)
     n_items = 0
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, torch.no_grad():
@@ -73,12 +74,18 @@ def run_inference(model: Callable[..., Mapping[str, torch.Tensor]], entries: Lis
             items = [f.result() for f in pending.pop(0)]
             batch = batcher.to_device(items)
             batch.update(model(**batch))                        # inferencer.py:117-118
-            if batch.get("s1") is not None:
-                for j, met in enumerate(metrics):               # inferencer.py:125-126
-                    sums[j] += float(met(**batch))
+            if batch.get("s1") is not None:                     # inferencer.py:125-126
+                if all(hasattr(met, "enqueue") for met in metrics):
+                    met_means.append([met.enqueue(**batch) for met in metrics])
+                else:
+                    for j, met in enumerate(metrics):
+                        sums[j] += float(met(**batch))
             if writer is not None:
                 writer.submit(batch, save_dir)                  # inferencer.py:128-147
             n_items += len(items)
+    for per_batch in met_means:
+        for j, (met, means) in enumerate(zip(metrics, per_batch)):
+            sums[j] += float(met.resolve(means.cpu()))
     paths = writer.close() if writer is not None else []
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0

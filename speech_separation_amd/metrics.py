@@ -69,6 +69,11 @@ class SiSNRWavLoss(torch.nn.Module):
 
 
 class SISNRMetric:
+    """``metric(**batch) -> value`` as the reference's (one launch, one device->host copy).  For a loop that must not stall
+    on every batch the call is also available in two halves: ``enqueue(**batch)`` launches the statistics kernel and
+    returns the (6,2) batch means as a DEVICE tensor without synchronising, ``resolve(means.cpu())`` finishes on the
+    host (evaluate.run_inference reads all batches' means once, at the end)."""
+
     def __init__(self, name=None, device="cuda", lower_better=False, *args, **kwargs):
         self.name = name if name is not None else type(self).__name__
         self.pick = min if lower_better else max
@@ -76,12 +81,21 @@ class SISNRMetric:
     def _pit(self, m):
         return self.pick(float((m[0] + m[3]) / 2), float((m[1] + m[2]) / 2))
 
+    def enqueue(self, s1_pred, s2_pred, s1, s2, mix=None, **batch) -> torch.Tensor:
+        stats = _engine(s1_pred.device).sisnr_pairs(s1_pred, s2_pred, s1, s2, s1_pred if mix is None else mix)
+        return stats.double().mean(0)
+
+    def resolve(self, means: torch.Tensor):
+        return self._pit(means[:, 0])
+
     def __call__(self, s1_pred, s2_pred, s1, s2, mix=None, **batch):
-        m = pair_statistics(s1_pred, s2_pred, s1, s2, s1_pred if mix is None else mix)[:, 0]
-        return self._pit(m)
+        return self.resolve(self.enqueue(s1_pred, s2_pred, s1, s2, mix).cpu())
 
 
 class SISNRiMetric(SISNRMetric):
-    def __call__(self, s1_pred, s2_pred, s1, s2, mix, **batch):
-        m = pair_statistics(s1_pred, s2_pred, s1, s2, mix)[:, 0]
+    def resolve(self, means: torch.Tensor):
+        m = means[:, 0]
         return torch.tensor(self._pit(m) - float((m[4] + m[5]) / 2))   # 0-dim tensor like the reference (float - tensor)
+
+    def __call__(self, s1_pred, s2_pred, s1, s2, mix, **batch):
+        return self.resolve(self.enqueue(s1_pred, s2_pred, s1, s2, mix).cpu())
