@@ -21,6 +21,8 @@ struct ALoadSeqShift {
   int lda, col0, bm;
   int shift;        // +1: previous position (forward direction), -1: next position (reverse direction)
   SeqGeom g;
+  unsigned magK;    // floor(2^32 / K) + 1: x / K == umulhi(x, magK) for x < K + bm  (make_seq_shift)
+  int sstride;      // rows between a token and its predecessor along the sequence, times shift
   DEV float4 load4(int tile, int row, int k4) const {
     const int64_t r = (int64_t)tile * bm + row;
     if (r >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -38,7 +40,33 @@ struct ALoadSeqShift {
     if (p2 < 0 || p2 >= g.len) return make_float4(0.f, 0.f, 0.f, 0.f);
     return *reinterpret_cast<const float4*>(A + src * lda + col0 + 4 * k4);
   }
+  // The same value without 64-bit divisions and without branches (rows are < 2^31: make_plan): the tile base is
+  // divided once per tile (wave-uniform), the row inside the tile by a multiply-high; outside the matrix / the sequence
+  // the load goes to row 0 and the result is replaced by zeros.  The weight-gradient kernels issue these between the
+  // MFMAs of a tile: with the branchy form above every load sat in its own basic block IN FRONT of the MFMA block and
+  // its ~130 instructions of address arithmetic were not overlapped with anything (one wave per SIMD).
+  DEV float4 load4z(int tile, int row, int k4) const {
+    const unsigned K = (unsigned)g.K, S = (unsigned)g.S;
+    const unsigned r0 = (unsigned)tile * (unsigned)bm;
+    const unsigned q0 = r0 / K, base = r0 - q0 * K;
+    const unsigned x = base + (unsigned)row;
+    const unsigned q1 = __umulhi(x, magK);
+    const unsigned k = x - q1 * K, rk = q0 + q1;
+    const unsigned pos = g.mode == 0 ? k : rk - (rk / S) * S;
+    const int p2 = (int)pos - shift;
+    const unsigned r = r0 + (unsigned)row;
+    const bool ok = r < (unsigned)M && p2 >= 0 && p2 < g.len;
+    const unsigned src = ok ? (unsigned)((int)r - sstride) : 0u;
+    const float4 v = *reinterpret_cast<const float4*>(A + (size_t)src * (unsigned)lda + (unsigned)(col0 + 4 * k4));
+    return mask4(v, ok);
+  }
 };
+static inline ALoadSeqShift make_seq_shift(const float* A, int64_t M, int lda, int col0, int bm, int shift, const SeqGeom& g) {
+  ALoadSeqShift l{A, M, lda, col0, bm, shift, g, 0u, 0};
+  l.magK = g.K > 1 ? (unsigned)((1ull << 32) / (unsigned)g.K) + 1u : 0u;   // K == 1: x / 1 is not a multiply-high; rejected by the caller
+  l.sstride = shift * (g.mode == 0 ? 1 : g.K);
+  return l;
+}
 
 // dense rows of a column slice [col0, col0 + width) of a token-major matrix.  RELU (ffn[0] applied while loading the raw
 // LSTM output the training tape keeps) is a COMPILE-TIME flag: as a runtime member it put a branch behind every load, the
@@ -56,8 +84,17 @@ struct ALoadColsT {
     if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     return v;
   }
+  // zero-filling like load4, branch-free like load4c (the load of a row beyond M goes to the last row and is discarded)
+  DEV float4 load4z(int tile, int row, int k4) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);   // wave-uniform
+    const bool ok = row <= last;
+    float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((ok ? row : last) * lda + col0 + 4 * k4));
+    if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return mask4(v, ok);
+  }
   // GEMM-engine form (rows beyond M are never stored there): clamped, branch-free.  The weight-gradient kernels need
-  // the zero-filling load4 above (padded rows must not contribute to the sums).
+  // the zero-filling load4 / load4z (padded rows must not contribute to the sums).
   DEV float4 load4c(int tile, int row, int k4) const {
     const int64_t r0 = (int64_t)tile * bm;
     const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);
@@ -79,6 +116,17 @@ struct WgradShape {
 
 // grid.x workgroups; slab[blockIdx.x][NN][KK] receives the partial sum of this workgroup's tiles.
 constexpr int wgrad_gcd(int a, int b) { return b == 0 ? a : wgrad_gcd(b, a % b); }
+
+// operand fetch of the weight-gradient kernels: the loader's branch-free zero-filling form where it has one
+template <class L, class = void>
+struct has_load4z : std::false_type {};
+template <class L>
+struct has_load4z<L, std::void_t<decltype(std::declval<const L&>().load4z(0, 0, 0))>> : std::true_type {};
+template <class L>
+DEV float4 wg_load(const L& l, int tile, int row, int k4) {
+  if constexpr (has_load4z<L>::value) return l.load4z(tile, row, k4);
+  else return l.load4(tile, row, k4);
+}
 
 // COLSUM: the column sums of Y (= the bias gradient of the same layer) ride along: every thread adds up the float4s it
 // stages (their column is the same for every tile), the workgroup combines them in a fixed order at the end into
@@ -122,10 +170,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   int tile = s_next[0];
   if (tile < ntiles) {
 #pragma unroll
-    for (int i = 0; i < NY; ++i) py[i] = yl.load4(tile, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+    for (int i = 0; i < NY; ++i) py[i] = wg_load(yl, tile, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) px[i] = xl.load4(tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+    for (int i = 0; i < NX; ++i) px[i] = wg_load(xl, tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
   }
+  // The 16 MFMA steps of a tile are ONE straight-line block: the fragments of step s+1 are read from LDS into the other
+  // register set before the MFMAs of step s, and the next tile's operand rows are fetched a few loads per step
+  // BETWEEN the MFMAs (a wave issues in order and is alone on its SIMD: address arithmetic in front of the block is
+  // time the matrix pipe idles, behind an MFMA it is free).  On the last tile the fetch re-reads that tile (clamped)
+  // instead of branching around the loads.
+  constexpr int NL = NY + NX, LPS = (NL + 7) / 8;   // all fetched in the first half of the block: their latency ends inside it
   int par = 0;
   while (tile < ntiles) {
     __syncthreads();                                   // previous tile's fragments fully consumed
@@ -146,41 +200,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
     if (tid == 0) s_next[par ^ 1] = ticket_ahead;   // publish the next ticket (requested one tile ago)
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
-    if (next < ntiles) {
-#pragma unroll
-      for (int i = 0; i < NY; ++i) py[i] = yl.load4(next, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) px[i] = xl.load4(next, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
-    }
-    // request the ticket after the next one here, in front of the MFMA block (as in gemm_ws.h: at the loop top it was
-    // the youngest memory operation when the staged registers are waited for)
+    const int nf = next < ntiles ? next : ntiles - 1;
     if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
     // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
+    float a[2][Sh::RB], b[2][Sh::CB];
+    auto frag = [&](int s, float* fa, float* fb) {
       const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;
       const float* xrow = Xs + (2 * s + hh) * Sh::LDX + c;
-      float a[Sh::RB], b[Sh::CB];
 #pragma unroll
-      for (int i = 0; i < Sh::RB; ++i) a[i] = yrow[(w + 4 * i) * 32];
+      for (int i = 0; i < Sh::RB; ++i) fa[i] = yrow[(w + 4 * i) * 32];
 #pragma unroll
-      for (int j = 0; j < Sh::CB; ++j) b[j] = xrow[j * 32];
+      for (int j = 0; j < Sh::CB; ++j) fb[j] = xrow[j * 32];
+    };
+    frag(0, a[0], b[0]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) frag(s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
+#pragma unroll
+      for (int q = 0; q < LPS; ++q) {
+        const int i = s * LPS + q;
+        if (i < NY) py[i] = wg_load(yl, nf, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+        else if (i < NL) px[i - NY] = wg_load(xl, nf, ((i - NY) * 256 + tid) / X4, ((i - NY) * 256 + tid) % X4);
+      }
 #pragma unroll
       for (int i = 0; i < Sh::RB; ++i)
 #pragma unroll
-        for (int j = 0; j < Sh::CB; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < Sh::CB; ++j) acc[i][j] = mfma32(a[s & 1][i], b[s & 1][j], acc[i][j]);
     }
     tile = next;
     par ^= 1;
   }
+  // partial tile in FRAGMENT order (wgrad_frag_index): four accumulator registers = one 16-byte store, a wave's store
+  // = 1 KiB contiguous.  Row-major order needed 16 x RB x CB dword stores per lane and the store queue, not the MFMA
+  // block, ended the kernel; slab_reduce_frag_kernel puts the sums back into row-major order.
   float* out = slab + (size_t)blockIdx.x * (NN * KK);
 #pragma unroll
   for (int i = 0; i < Sh::RB; ++i)
 #pragma unroll
     for (int j = 0; j < Sh::CB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        out[(size_t)((w + 4 * i) * 32 + ROW32(r, hh)) * KK + j * 32 + c] = acc[i][j][r];
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(out + ((((size_t)(w * Sh::RB + i) * Sh::CB + j) * 4 + g4) * 64 + lane) * 4) =
+            make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
   if constexpr (COLSUM) {
     // thread tid's accumulator k belongs to column block (k*256 + tid) % Y4; owner thread cb sums its contributors in
     // (k, tid) order -- a fixed association order
@@ -235,16 +296,17 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
   }
   __syncthreads();
   int tile = s_next[0];
-  auto fetch = [&](int t) {
+  if (tile < ntiles) {
 #pragma unroll
-    for (int i = 0; i < NY; ++i) py[i] = yl.load4(t, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+    for (int i = 0; i < NY; ++i) py[i] = wg_load(yl, tile, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      pxa[i] = xa.load4(t, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
-      pxb[i] = xb.load4(t, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+      pxa[i] = wg_load(xa, tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+      pxb[i] = wg_load(xb, tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
     }
-  };
-  if (tile < ntiles) fetch(tile);
+  }
+  // straight-line tile block as in wgrad_kernel: fragments double buffered, next tile's rows fetched between the MFMAs
+  constexpr int NL = NY + 2 * NX, LPS = (NL + 7) / 8;
   int par = 0;
   while (tile < ntiles) {
     __syncthreads();
@@ -262,27 +324,38 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
     if (tid == 0) s_next[par ^ 1] = ticket_ahead;
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
-    if (next < ntiles) fetch(next);
+    const int nf = next < ntiles ? next : ntiles - 1;
     if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
-#pragma unroll 2
-    for (int s = 0; s < 16; ++s) {
+    float a[2][Sh::RB], ba[2][Sh::CB], bb[2][Sh::CB];
+    auto frag = [&](int s, float* fa, float* fba, float* fbb) {
       const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;
       const float* xarow = Xas + (2 * s + hh) * Sh::LDX + c;
       const float* xbrow = Xbs + (2 * s + hh) * Sh::LDX + c;
-      float a[Sh::RB], ba[Sh::CB], bb[Sh::CB];
 #pragma unroll
-      for (int i = 0; i < Sh::RB; ++i) a[i] = yrow[(w + 4 * i) * 32];
+      for (int i = 0; i < Sh::RB; ++i) fa[i] = yrow[(w + 4 * i) * 32];
 #pragma unroll
       for (int j = 0; j < Sh::CB; ++j) {
-        ba[j] = xarow[j * 32];
-        bb[j] = xbrow[j * 32];
+        fba[j] = xarow[j * 32];
+        fbb[j] = xbrow[j * 32];
+      }
+    };
+    frag(0, a[0], ba[0], bb[0]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) frag(s + 1, a[(s + 1) & 1], ba[(s + 1) & 1], bb[(s + 1) & 1]);
+#pragma unroll
+      for (int q = 0; q < LPS; ++q) {
+        const int i = s * LPS + q;
+        if (i < NY) py[i] = wg_load(yl, nf, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+        else if (i < NY + NX) pxa[i - NY] = wg_load(xa, nf, ((i - NY) * 256 + tid) / X4, ((i - NY) * 256 + tid) % X4);
+        else if (i < NL) pxb[i - NY - NX] = wg_load(xb, nf, ((i - NY - NX) * 256 + tid) / X4, ((i - NY - NX) * 256 + tid) % X4);
       }
 #pragma unroll
       for (int i = 0; i < Sh::RB; ++i)
 #pragma unroll
         for (int j = 0; j < Sh::CB; ++j) {
-          acca[i][j] = mfma32(a[i], ba[j], acca[i][j]);
-          accb[i][j] = mfma32(a[i], bb[j], accb[i][j]);
+          acca[i][j] = mfma32(a[s & 1][i], ba[s & 1][j], acca[i][j]);
+          accb[i][j] = mfma32(a[s & 1][i], bb[s & 1][j], accb[i][j]);
         }
     }
     tile = next;
@@ -295,10 +368,12 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
 #pragma unroll
     for (int j = 0; j < Sh::CB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const size_t o = (size_t)((w + 4 * i) * 32 + ROW32(r, hh)) * KK + j * 32 + c;
-        outa[o] = acca[i][j][r];
-        outb[o] = accb[i][j][r];
+      for (int g4 = 0; g4 < 4; ++g4) {   // fragment order, as wgrad_kernel
+        const size_t o = ((((size_t)(w * Sh::RB + i) * Sh::CB + j) * 4 + g4) * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(outa + o) =
+            make_float4(acca[i][j][4 * g4], acca[i][j][4 * g4 + 1], acca[i][j][4 * g4 + 2], acca[i][j][4 * g4 + 3]);
+        *reinterpret_cast<float4*>(outb + o) =
+            make_float4(accb[i][j][4 * g4], accb[i][j][4 * g4 + 1], accb[i][j][4 * g4 + 2], accb[i][j][4 * g4 + 3]);
       }
 }
 
@@ -356,30 +431,47 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
-// same, slabs `stride` floats apart (two interleaved partial tiles per workgroup: wgrad2_kernel), overwrite only
-__global__ __launch_bounds__(256) void slab_reduce_strided_kernel(const float* __restrict__ slab, int nslabs, int64_t count,
-                                                                   int64_t stride, float* __restrict__ out) {
-  __shared__ float red[8][32];
+// Sum of the weight-gradient kernels' partial tiles, which are stored in fragment order: float4 number
+//   f = (((w * RB + i) * CB + j) * 4 + g4) * 64 + lane      holds rows (w + 4 i) * 32 + 8 g4 + 4 (lane / 32) + 0..3
+//                                                            of column j * 32 + lane % 32.
+// A workgroup owns 32 consecutive float4s; its 8 slab-lanes sum the slabs s = lane, lane + 8, ... with four 16-byte
+// loads in flight (fixed association order), then thread e < 32 combines the lanes in lane order and writes its four
+// rows of dW[NN][KK].  slabs are `stride` floats apart.
+template <int RB, int CB>
+__global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float* __restrict__ slab, int nslabs, int64_t stride,
+                                                                float* __restrict__ out) {
+  constexpr int KK = CB * 32;
+  __shared__ float4 red[8][32];
   const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + e;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < count) {
-    int k = sl;
-    for (; k + 24 < nslabs; k += 32) {
-      s0 += slab[(size_t)k * stride + i];
-      s1 += slab[(size_t)(k + 8) * stride + i];
-      s2 += slab[(size_t)(k + 16) * stride + i];
-      s3 += slab[(size_t)(k + 24) * stride + i];
-    }
-    for (; k < nslabs; k += 8) s0 += slab[(size_t)k * stride + i];
+  const int f = blockIdx.x * 32 + e;                 // grid = 4 * RB * CB * 4 * 64 / 32 exactly
+  const float4* src = reinterpret_cast<const float4*>(slab) + f;
+  const int64_t st4 = stride / 4;
+  auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  int k = sl;
+  for (; k + 24 < nslabs; k += 32) {
+    add(s0, src[(int64_t)k * st4]);
+    add(s1, src[(int64_t)(k + 8) * st4]);
+    add(s2, src[(int64_t)(k + 16) * st4]);
+    add(s3, src[(int64_t)(k + 24) * st4]);
   }
-  red[sl][e] = (s0 + s1) + (s2 + s3);
+  for (; k < nslabs; k += 8) add(s0, src[(int64_t)k * st4]);
+  add(s0, s1);
+  add(s2, s3);
+  add(s0, s2);
+  red[sl][e] = s0;
   __syncthreads();
-  if (sl == 0 && i < count) {
-    float s = 0.f;
+  if (sl == 0) {
+    float4 s = red[0][e];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += red[j][e];
-    out[i] = s;
+    for (int j = 1; j < 8; ++j) add(s, red[j][e]);
+    const int lane = f & 63, g4 = (f >> 6) & 3, t = f >> 8;          // t = (w * RB + i) * CB + j
+    const int j = t % CB, wi = t / CB, i = wi % RB, w = wi / RB;
+    const int row = (w + 4 * i) * 32 + 8 * g4 + 4 * (lane >> 5), col = j * 32 + (lane & 31);
+    out[(size_t)row * KK + col] = s.x;
+    out[(size_t)(row + 1) * KK + col] = s.y;
+    out[(size_t)(row + 2) * KK + col] = s.z;
+    out[(size_t)(row + 3) * KK + col] = s.w;
   }
 }
 

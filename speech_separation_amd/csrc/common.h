@@ -12,6 +12,8 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -127,6 +129,14 @@ struct DropCfg {
 // Sequence geometry of one TransformerDPRNN call over the token tensor x[b][s][k][n].
 //   mode 0 (intra-chunk): sequence q = b*S + s, position t = k   -> token q*K + t
 //   mode 1 (inter-chunk): sequence q = b*K + k, position t = s   -> token (b*S + t)*K + k
+// v where keep, zeros elsewhere, as a bit mask: written as a select on the loaded value the compiler turns it back into
+// a branch around the load (a basic block per load; see ALoadSeqShift::load4z)
+DEV float4 mask4(float4 v, bool keep) {
+  const unsigned m = keep ? 0xffffffffu : 0u;
+  return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                     __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
+
 struct SeqGeom {
   int mode;
   int B, S, K;

@@ -95,8 +95,10 @@ struct dptnav_ctx {
     d.inv_keep = (float)(1.0 / (1.0 - p));
     return d;
   }
-  hipStream_t streams[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
+  static constexpr int NSTREAMS = 4;   // internal streams (dptnav_forward uses min(sub-batches, NSTREAMS); training two)
+  hipStream_t streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
+  int opt_sub_batches = 0;          // 0: forward_split decides; n > 0: that many sub-batches (experiments)
   std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
   int ensure_sub_events(int n) {
     while ((int)ev_sub.size() < n) {
@@ -108,10 +110,10 @@ struct dptnav_ctx {
   }
   int ensure_streams() {
     if (streams[0]) return 0;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NSTREAMS; ++i) {
       if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_lstm[i], hipEventDisableTiming) != hipSuccess) {
+          (i < 2 && hipEventCreateWithFlags(&ev_lstm[i], hipEventDisableTiming) != hipSuccess)) {
         err = "cannot create internal streams/events";
         return 4;
       }
@@ -779,9 +781,9 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab, (float*)nullptr);
   }
   LAUNCH_CHECK(c, what);
-  const int64_t count = (int64_t)NN * KK;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count,
-                     grad, 0);
+  constexpr int64_t count = (int64_t)NN * KK;
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st, slab, grid,
+                     count, grad);
   if (bias_grad)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((NN + 31) / 32), dim3(256), 0, br.st, colslab, grid, (int64_t)NN, bias_grad, 0);
   LAUNCH_CHECK(c, what);
@@ -804,13 +806,12 @@ int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, c
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xa, xb, slab);
   LAUNCH_CHECK(c, what);
-  const int64_t count = (int64_t)NN * KK;
-  // slab_reduce walks slabs with stride `count`: here a workgroup's two partial tiles are 2*count apart -> view the
-  // region as 2*grid slabs and reduce the even / odd ones (nslabs = grid, stride 2*count) through the `stride` form
-  hipLaunchKernelGGL(slab_reduce_strided_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count,
+  constexpr int64_t count = (int64_t)NN * KK;
+  // a workgroup's two partial tiles lie 2 * count floats from the next workgroup's
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st, slab, grid,
                      2 * count, gradA);
-  hipLaunchKernelGGL(slab_reduce_strided_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab + count, grid, count,
-                     2 * count, gradB);
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st,
+                     slab + count, grid, 2 * count, gradB);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -910,7 +911,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
                        (int64_t)512, G(bhh.c_str()), 0);
     LAUNCH_CHECK(c, "d lstm bias");
     ALoadDense xl{y1, M, N, 32};
-    ALoadSeqShift hl{hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom};
+    const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
       ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
       if (c->opt_wgrad2) {   // W_ih and W_hh gradients in ONE pass over dP
@@ -1171,11 +1172,11 @@ int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st
 
 // Join the caller's stream to BOTH internal streams (always, also after a failed enqueue: kernels already queued there
 // must be ordered before whatever the caller does next) and return the body's error, or the join's if the body was fine.
-int join_after(dptnav_ctx* c, hipStream_t st, bool forked, int rc_body) {
+int join_after(dptnav_ctx* c, hipStream_t st, bool forked, int rc_body, int nstreams = 2) {
   if (!forked) return rc_body;
   const std::string body_err = c->err;
   bool ok = true;
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < nstreams; ++s)
     ok &= hipEventRecord(c->ev_join[s], c->streams[s]) == hipSuccess && hipStreamWaitEvent(st, c->ev_join[s], 0) == hipSuccess;
   if (rc_body) {
     c->err = body_err;
@@ -1238,10 +1239,10 @@ void dptnav_destroy(dptnav_handle h) {
   if (!h) return;
   for (ProfRec& r : h->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < dptnav_ctx::NSTREAMS; ++i) {
     if (h->streams[i]) hipStreamDestroy(h->streams[i]);
     if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
-    if (h->ev_lstm[i]) hipEventDestroy(h->ev_lstm[i]);
+    if (i < 2 && h->ev_lstm[i]) hipEventDestroy(h->ev_lstm[i]);
   }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (hipEvent_t e : h->ev_sub) hipEventDestroy(e);
@@ -1297,6 +1298,7 @@ static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes) 
     while (bfit < B && fits(bfit + 1)) ++bfit;
     if (bfit >= 4) nsub = std::max(2, (B + bfit - 1) / bfit);
   }
+  if (h->opt_sub_batches > 0) nsub = h->opt_sub_batches;
   if (nsub > MAX_SUB) nsub = MAX_SUB;
   if (nsub > B) nsub = B;
   for (int i = 0; i < nsub; ++i) sizes[i] = B / nsub + (i < B % nsub ? 1 : 0);
@@ -1397,11 +1399,13 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   }
   if (ws_bytes < need * sizeof(float))
     return h->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need * sizeof(float));
+  // sub-batches go round robin over min(nsub, NSTREAMS) internal streams (two for the default two halves)
+  const int nstr = std::min(nsub, (int)dptnav_ctx::NSTREAMS);
   if (nsub > 1) {
     if (int rc = h->ensure_streams()) return rc;
     if (int rc = h->ensure_sub_events(nsub)) return rc;
     if (hipEventRecord(h->ev_fork, st) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork event");
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < nstr; ++s)
       if (hipStreamWaitEvent(h->streams[s], h->ev_fork, 0) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork wait");
   }
   const int64_t Cv = g.audio_only ? 0 : g.video_emb_size;
@@ -1414,7 +1418,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   auto enqueue = [&]() -> int {
   int64_t b0 = 0;
   for (int i = 0; i < nsub; ++i) {
-    hipStream_t si = nsub > 1 ? h->streams[i & 1] : st;   // sub-batches alternate between the two streams
+    hipStream_t si = nsub > 1 ? h->streams[i % nstr] : st;   // sub-batches go round robin over the internal streams
     if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
     mixi[i] = mix + b0 * T;
     e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
@@ -1467,7 +1471,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   return DPTNAV_OK;
   };
   const int rc_body = enqueue();
-  return join_after(h, st, nsub > 1, rc_body);
+  return join_after(h, st, nsub > 1, rc_body, nstr);
 }
 
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* off, size_t* numel) {
@@ -1900,6 +1904,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "fold_tail") h->opt_fold_tail = value != 0;
+  else if (k == "sub_batches" && value >= 0 && value <= MAX_SUB) h->opt_sub_batches = value;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;

@@ -389,6 +389,14 @@ struct ALoadDense {
     const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);   // wave-uniform
     return *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((row < last ? row : last) * lda + 4 * k4));
   }
+  // zero-filling like load4, branch-free like load4c (weight-gradient kernels: loads issued between MFMAs)
+  DEV float4 load4z(int tile, int row, int k4) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);
+    const bool ok = row <= last;
+    const float4 v = *reinterpret_cast<const float4*>(A + r0 * lda + (unsigned)((ok ? row : last) * lda + 4 * k4));
+    return mask4(v, ok);
+  }
 };
 
 // dense rows with PReLU applied on the fly (dptn_wav.py:27 -- single shared slope)
