@@ -266,10 +266,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
 // Two weight gradients that share their Y operand in ONE pass over Y:  dWa = sum Y^T Xa,  dWb = sum Y^T Xb  (the LSTM's
 // W_ih and W_hh gradients: Y = dP, Xa = the layer input, Xb = h_{t-1}).  The Y tile is staged and its fragments are
 // read once for 2 x CB MFMAs each; 2 x RB x CB accumulator tiles per wave (256 registers for <256,128>: they live in
-// the AGPR half, one workgroup per CU as before).  slab[blockIdx.x][2][NN][KK].
-template <int NN, int KK, class YLoad, class XLoadA, class XLoadB>
-__global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __restrict__ queue, YLoad yl, XLoadA xa, XLoadB xb,
-                                                      float* __restrict__ slab) {
+// the AGPR half, one workgroup per CU as before).
+// NSL independent problems ("slices": the 2 directions x 2 halves of the 512 gate rows) share ONE launch: workgroup b
+// works on slice b % NSL with its own ticket counter, so a slice is summed by gridDim.x / NSL workgroups that each
+// take NSL times more tiles than with one launch per slice.  What that buys is the END of the kernel: a workgroup's
+// partial tiles are 256 KB, a CU stores ~7-11 B/cycle, and in-kernel stamps put that store tail at 64 k cycles against
+// 20 tiles x 16.4 k cycles of MFMAs per launch (14 %); now it is paid once per 83 tiles, and the slabs to reduce are
+// NSL times fewer.   slab[slice][gridDim.x / NSL][2][NN x KK in fragment order].
+template <class YLoad, class XLoadA, class XLoadB, int NSL>
+struct Wgrad2Args {
+  YLoad yl[NSL];
+  XLoadA xa[NSL];
+  XLoadB xb[NSL];
+};
+template <int NN, int KK, class YLoad, class XLoadA, class XLoadB, int NSL>
+__global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __restrict__ queue_base,
+                                                      const Wgrad2Args<YLoad, XLoadA, XLoadB, NSL> args,
+                                                      float* __restrict__ slab_base) {
+  const int sl = blockIdx.x % NSL;
+  const YLoad yl = args.yl[sl];
+  const XLoadA xa = args.xa[sl];
+  const XLoadB xb = args.xb[sl];
+  unsigned* queue = queue_base + sl;
+  float* slab = slab_base + (size_t)sl * (gridDim.x / NSL) * (2 * NN * KK);
+  const int wg = blockIdx.x / NSL;
   using Sh = WgradShape<NN, KK>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_next = reinterpret_cast<int*>(smem);
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
     tile = next;
     par ^= 1;
   }
-  float* outa = slab + (size_t)blockIdx.x * (2 * NN * KK);
+  float* outa = slab + (size_t)wg * (2 * NN * KK);
   float* outb = outa + NN * KK;
 #pragma unroll
   for (int i = 0; i < Sh::RB; ++i)
@@ -431,20 +451,91 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// slab_reduce_kernel with two destinations (overwrite): split >= 0: elements [0, split) go to out_a, the rest to out_b
+// (LayerNorm: d gamma | d beta from one slab row); split < 0: every element goes to both (b_ih and b_hh have the same
+// gradient).  Same association order as slab_reduce_kernel.
+__global__ __launch_bounds__(256) void slab_reduce_to2_kernel(const float* __restrict__ slab, int nslabs, int64_t count,
+                                                               float* __restrict__ out_a, float* __restrict__ out_b, int split) {
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    int k = sl;
+    for (; k + 24 < nslabs; k += 32) {
+      s0 += slab[(size_t)k * count + i];
+      s1 += slab[(size_t)(k + 8) * count + i];
+      s2 += slab[(size_t)(k + 16) * count + i];
+      s3 += slab[(size_t)(k + 24) * count + i];
+    }
+    for (; k < nslabs; k += 8) s0 += slab[(size_t)k * count + i];
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && i < count) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][e];
+    if (split < 0) {
+      out_a[i] = s;
+      out_b[i] = s;
+    } else if (i < split) {
+      out_a[i] = s;
+    } else {
+      out_b[i - split] = s;
+    }
+  }
+}
+
 // Sum of the weight-gradient kernels' partial tiles, which are stored in fragment order: float4 number
 //   f = (((w * RB + i) * CB + j) * 4 + g4) * 64 + lane      holds rows (w + 4 i) * 32 + 8 g4 + 4 (lane / 32) + 0..3
 //                                                            of column j * 32 + lane % 32.
 // A workgroup owns 32 consecutive float4s; its 8 slab-lanes sum the slabs s = lane, lane + 8, ... with four 16-byte
 // loads in flight (fixed association order), then thread e < 32 combines the lanes in lane order and writes its four
-// rows of dW[NN][KK].  slabs are `stride` floats apart.
+// rows of dW[NN][KK].  slabs are `stride` floats apart.  Several sums per launch (blockIdx.y, at most 8).
+struct FragOuts {
+  float* out[8];
+};
+// blockIdx.y = which sum: its slabs start at slab + (y / per_group) * group_stride + (y % per_group) * RB*CB*4096
+// Workgroups beyond the RB*CB*32 of the tiles (blockIdx.y == 0 only) sum the column-sum rows colslab[nslabs][ncol] of the
+// same launch (the bias gradient) the slab_reduce_kernel way.
 template <int RB, int CB>
 __global__ __launch_bounds__(256) void slab_reduce_frag_kernel(const float* __restrict__ slab, int nslabs, int64_t stride,
-                                                                float* __restrict__ out) {
+                                                                FragOuts outs, int64_t group_stride, int per_group,
+                                                                const float* __restrict__ colslab, int ncol,
+                                                                float* __restrict__ bias_out) {
   constexpr int KK = CB * 32;
   __shared__ float4 red[8][32];
   const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int f = blockIdx.x * 32 + e;                 // grid = 4 * RB * CB * 4 * 64 / 32 exactly
-  const float4* src = reinterpret_cast<const float4*>(slab) + f;
+  if (blockIdx.x >= RB * CB * 32) {                  // wave-uniform: bias part
+    if (blockIdx.y != 0) return;
+    float* redf = reinterpret_cast<float*>(red);
+    const int i = (blockIdx.x - RB * CB * 32) * 32 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < ncol) {
+      int k = sl;
+      for (; k + 24 < nslabs; k += 32) {
+        s0 += colslab[(size_t)k * ncol + i];
+        s1 += colslab[(size_t)(k + 8) * ncol + i];
+        s2 += colslab[(size_t)(k + 16) * ncol + i];
+        s3 += colslab[(size_t)(k + 24) * ncol + i];
+      }
+      for (; k < nslabs; k += 8) s0 += colslab[(size_t)k * ncol + i];
+    }
+    redf[sl * 32 + e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < ncol) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += redf[j * 32 + e];
+      bias_out[i] = s;
+    }
+    return;
+  }
+  const int f = blockIdx.x * 32 + e;
+  const int y = blockIdx.y;
+  float* __restrict__ out = outs.out[y];
+  const float4* src = reinterpret_cast<const float4*>(slab + (y / per_group) * group_stride + (int64_t)(y % per_group) * (RB * CB * 4096)) + f;
   const int64_t st4 = stride / 4;
   auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;

@@ -782,36 +782,44 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
   }
   LAUNCH_CHECK(c, what);
   constexpr int64_t count = (int64_t)NN * KK;
-  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st, slab, grid,
-                     count, grad);
-  if (bias_grad)
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((NN + 31) / 32), dim3(256), 0, br.st, colslab, grid, (int64_t)NN, bias_grad, 0);
+  FragOuts outs{};
+  outs.out[0] = grad;
+  // the bias gradient's column sums are reduced by extra workgroups of the same launch
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128) + (bias_grad ? (NN + 31) / 32 : 0)),
+                     dim3(256), 0, br.st, slab, grid, count, outs, (int64_t)0, 1, colslab, bias_grad ? NN : 0, bias_grad);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
 
-// two gradients sharing the Y operand in one pass (wgrad2_kernel): gradA = sum Y^T Xa, gradB = sum Y^T Xb
-template <int NN, int KK, class YL, class XA, class XB>
-int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XA& xa, const XB& xb,
-                  float* gradA, float* gradB) {
+// NSL pairs of gradients, each pair sharing its Y operand, in one pass and ONE launch (wgrad2_kernel):
+// gradA[s] = sum Y_s^T Xa_s, gradB[s] = sum Y_s^T Xb_s
+template <int NN, int KK, int NSL, class YL, class XA, class XB>
+int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const Wgrad2Args<YL, XA, XB, NSL>& args,
+                  float* const* gradA, float* const* gradB) {
   const size_t lds = sizeof(float) * (4 + 32 * (size_t)(WgradShape<NN, KK>::LDY + 2 * WgradShape<NN, KK>::LDX));
-  const int grid = cap_grid(ntiles, br.pl.slab_wgs);
-  float* slab = br.ws + br.pl.slab;            // [grid][2][NN][KK]: BWD_SLAB_WGS x 512 x 128 floats hold <256,128> exactly
+  static_assert(2 * NSL <= 8, "FragOuts");
+  int grid = cap_grid(ntiles * NSL, br.pl.slab_wgs);
+  grid -= grid % NSL;                          // the same number of workgroups for every slice
+  if (grid < NSL) grid = NSL;
+  float* slab = br.ws + br.pl.slab;            // [NSL][grid / NSL][2][NN][KK]: BWD_SLAB_WGS x 512 x 128 floats hold <256,128> exactly
   static_assert(2 * NN * KK <= 512 * 128, "slab size");
-  auto kern = wgrad2_kernel<NN, KK, YL, XA, XB>;
+  auto kern = wgrad2_kernel<NN, KK, YL, XA, XB, NSL>;
   static PerDeviceOnce ready;
   if (!ready.done(c->device_id)) {
     if (int rc = set_lds(c, kern, lds, what)) return rc;
     ready.set(c->device_id);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xa, xb, slab);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(NSL), args, slab);
   LAUNCH_CHECK(c, what);
   constexpr int64_t count = (int64_t)NN * KK;
-  // a workgroup's two partial tiles lie 2 * count floats from the next workgroup's
-  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st, slab, grid,
-                     2 * count, gradA);
-  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128)), dim3(256), 0, br.st,
-                     slab + count, grid, 2 * count, gradB);
+  FragOuts outs{};
+  for (int s = 0; s < NSL; ++s) {
+    outs.out[2 * s] = gradA[s];
+    outs.out[2 * s + 1] = gradB[s];
+  }
+  // sum y = (slice, a / b): the slabs of a slice are 2 * count apart, a slice's region is (grid / NSL) of them
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128), 2 * NSL), dim3(256), 0, br.st, slab,
+                     grid / NSL, 2 * count, outs, (int64_t)(grid / NSL) * 2 * count, 2, (const float*)nullptr, 0, (float*)nullptr);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -864,9 +872,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<2 * LSTM_H, 1, 1, 4>(c, run, CAT_FFN, "ffn recompute + ln2 bwd", w.ffn_w, ntiles, 1, al, ep,
                                                  nullptr, 2 * LSTM_H, &grid))
       return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
-    hipMemcpyAsync(G("ln2.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(G("ln2.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, G("ln2.weight"),
+                       G("ln2.bias"), N);
     LAUNCH_CHECK(c, "ln2 grads");
   }
   br.slot = run.slot;
@@ -900,31 +907,36 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   if (br.lstm_record && hipEventRecord(br.lstm_record, st) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger record");
   // 5. LSTM parameter gradients
+  Wgrad2Args<ALoadCols, ALoadDense, ALoadSeqShift, 4> wa{};
+  float *gA[4], *gB[4];
   for (int d = 0; d < 2; ++d) {
     const char* sfx = d ? "_reverse" : "";
     const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
                       bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
     // bias gradients: per-workgroup partial rows written by the BPTT kernel
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl,
-                       (int64_t)512, G(bih.c_str()), 0);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl,
-                       (int64_t)512, G(bhh.c_str()), 0);
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl,
+                       (int64_t)512, G(bih.c_str()), G(bhh.c_str()), -1);
     LAUNCH_CHECK(c, "d lstm bias");
-    ALoadDense xl{y1, M, N, 32};
+    const ALoadDense xl{y1, M, N, 32};
     const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
-      ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
-      if (c->opt_wgrad2) {   // W_ih and W_hh gradients in ONE pass over dP
+      const ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
+      if (c->opt_wgrad2) {   // W_ih and W_hh gradients in ONE pass over dP; the four (direction, half) slices in one launch
         static_assert(N == LSTM_H, "wgrad2 pairs two operands of equal width");
-        if (int rc = launch_wgrad2<256, N>(c, br, "d w_ih + d w_hh", ntiles, yl, xl, hl, G(wih.c_str()) + half * 256 * N,
-                                           G(whh.c_str()) + half * 256 * LSTM_H))
-          return rc;
+        const int s4 = 2 * d + half;
+        wa.yl[s4] = yl;
+        wa.xa[s4] = xl;
+        wa.xb[s4] = hl;
+        gA[s4] = G(wih.c_str()) + half * 256 * N;
+        gB[s4] = G(whh.c_str()) + half * 256 * LSTM_H;
       } else {
         if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
         if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
       }
     }
   }
+  if (c->opt_wgrad2)
+    if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB)) return rc;
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
   run.slot = br.slot;
   for (int d = 0; d < 2; ++d) {
@@ -940,9 +952,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_OUTPROJ, "out-proj recompute + ln1 bwd", w.out_w, ntiles, 1, al, ep,
                                         nullptr, N, &grid))
       return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, br.ws + br.pl.slab, 0);
-    hipMemcpyAsync(G("ln1.weight"), br.ws + br.pl.slab, N * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(G("ln1.bias"), br.ws + br.pl.slab + N, N * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)2 * N, G("ln1.weight"),
+                       G("ln1.bias"), N);
     LAUNCH_CHECK(c, "ln1 grads");
   }
   br.slot = run.slot;
