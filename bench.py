@@ -63,15 +63,16 @@ def host_cores() -> int:
 
 
 PMC_TABLE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r02_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
 
 
-def pmc_table(config: str):
+def pmc_table(config: str, path: str = None):
     """The committed per-kernel HBM-traffic table (tools/pmc_table.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes over `bench.py --pmc-run`, gfx950 corrections applied; its header names the commit and the command it was taken
     at).  bench.py cannot read PMC counters itself, so `traffic` figures are FROM THIS FILE, for the configuration it was
     measured on only (anything else reports null)."""
     try:
-        d = json.load(open(PMC_TABLE))
+        d = json.load(open(path or PMC_TABLE))
         return d if d.get("config") == config else None
     except (OSError, ValueError):
         return None
@@ -218,6 +219,7 @@ def bench_train(args, env, cfg, B, T, workload):
     eng.profile(False)
     if env.rank == 0:
         value = env.world * B * args.steps / elapsed
+        ttab = pmc_table(args.config, PMC_TABLE_TRAIN)
         flops = 3.0 * eng.flops_per_mixture(T)            # forward + backward (dgrad + wgrad), recomputes not counted
         print(json.dumps({
             "metric": "mixtures/sec DPTN-AV training step (fwd + PIT SI-SNR loss + bwd + clip + AdamW)",
@@ -229,7 +231,11 @@ def bench_train(args, env, cfg, B, T, workload):
                        "parallelism": f"dp{env.world} (one flat gradient all-reduce per step over RCCL)"},
             "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": round(value / env.world * flops / 1e12, 3),
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(value / env.world * flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(value / env.world * flops / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": ttab["bytes_per_step"] if ttab and B == ttab.get("batch") and T == ttab.get("samples") else None,
+                         "traffic_unit": (f"HBM bytes per optimizer step per GPU, from {os.path.relpath(PMC_TABLE_TRAIN, ROOT)} "
+                                          f"(PMC FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, commit {ttab.get('commit', '?')})")
+                         if ttab else None,
                          "note": "algorithmic FLOPs = 3 x forward (612 GFLOP per mixture)"},
             "kernels_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in prof.items()},
             "last_step": {k: round(float(v), 5) for k, v in stats.items()} if stats else None,

@@ -224,7 +224,12 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "fold_tail" (0/1, default 1): inference computes the decoder tap products as ONE contraction per frame,
  *                 [OLA(mask) | encoded] . [W_dec^T W_post | W_dec^T] + W_dec^T b_post (folded from the current weights on
  *                 every call), instead of the post-processing GEMM with a k-reduction epilogue.
- *   "wgrad2" (0/1, default 1): training computes the W_ih and W_hh gradients of an LSTM in one pass over dP.
+ *   "wgrad2" (0/1, default 1): training computes the W_ih and W_hh gradients of an LSTM in one pass over dP, the four
+ *                 (direction, gate-row half) problems of a path in one launch; 0 = eight single-gradient launches.
+ *   "sub_batches" (0..32, default 0): how many sub-batches dptnav_forward cuts a batch into; 0 = its own rule (as few
+ *                 as make every recurrence launch fit the chip in one round, at least two).  A measurement knob
+ *                 (tools/subbatch_sweep.py): results of different cuts agree to fp32 rounding, not bit for bit.  Set it
+ *                 before dptnav_workspace_bytes -- the workspace is sized for the cut.
  *   "split_bf16" (0/1, default 0): OPT-IN experiment, never a parity claim -- the 16-sequence-tile recurrence of the
  *                 inference forward runs on bf16 MFMAs with every operand split into bf16 hi + lo (three products, fp32
  *                 accumulation: ~2^-17 relative error per product instead of 2^-24, ~5x less matrix time); lstm16s.hip.
