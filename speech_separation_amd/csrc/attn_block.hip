@@ -37,6 +37,55 @@ constexpr int LDX = N + 4;                  // token rows: conflict-free ds_read
 constexpr int LDP = 136;                    // partial-tile row stride: rows 4 apart (the two lane halves) are 32 banks apart
 
 DEV float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// group_sum<32> of FOUR independent values, step by step side by side: one reduction is a chain of five dependent
+// cross-lane operations (each waits out the previous one's result), and the row-space code was four such passes one
+// after the other -- 2.6-2.9 k cycles per 32-row block in the phase stamps (tools/attn_stamps.py).
+DEV void group_sum32_x4(float (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp_move<0xB1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp_move<0x4E>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp_move<0x141>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp_move<0x140>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned u = __builtin_bit_cast(unsigned, v[i]);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v[i] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  }
+}
+// LayerNorm of four rows at once: v[i] = this lane's 4 columns of row i (a row = 32 adjacent lanes)
+DEV void layernorm_rows_x4(float4 (&v)[4], const float4 ga, const float4 be) {
+  float s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  group_sum32_x4(s);
+  float q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float mu = s[i] * (1.0f / N);
+    v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
+    q[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  group_sum32_x4(q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float rstd = rsqrtf(q[i] * (1.0f / N) + 1e-5f);
+    v[i] = make_float4(v[i].x * rstd * ga.x + be.x, v[i].y * rstd * ga.y + be.y, v[i].z * rstd * ga.z + be.z, v[i].w * rstd * ga.w + be.w);
+  }
+}
+// MFMAs issued by iteration kb of the softmax pipeline: PV(kb-1) (kb > 0) + S(kb+1) (kb + 1 < nkb), 16 each
+constexpr int kb_mfmas(int kb, int nkb) { return (kb > 0 ? 16 : 0) + (kb + 1 < nkb ? 16 : 0); }
+template <class F, int... I>
+DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, class F>
+DEV void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N_>{});
+}
 
 // max / sum across the two 32-lane halves (lanes (c,0) and (c,1) hold the two halves of a query's keys)
 DEV float half_max(float v) {
@@ -65,9 +114,33 @@ struct FfnPro {
 };
 constexpr int LDHC = 256 + 4;
 
+// Phase stamps (diagnostic build only: -DATTN_STAMPS, tools/attn_stamps.py): s_memtime sums per phase and wave,
+// added up over all waves of all launches in g_ab_stamps.  The product build compiles them to nothing.
+#ifdef ATTN_STAMPS
+__device__ unsigned long long g_ab_stamps[16];
+DEV unsigned long long ab_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define AB_DECL unsigned long long ab_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ab_last = ab_now();
+#define AB_MARK(i) { const unsigned long long ab_n = ab_now(); ab_t[i] += ab_n - ab_last; ab_last = ab_n; }
+#define AB_KEEP(x) asm volatile("" :: "v"(x));
+#define AB_END                                                                                      \
+  if ((threadIdx.x & 63) == 0) {                                                                    \
+    for (int ab_i = 0; ab_i < 12; ++ab_i) atomicAdd(&g_ab_stamps[ab_i], ab_t[ab_i]);                \
+    atomicAdd(&g_ab_stamps[12], 1ull);                                                              \
+  }
+#else
+#define AB_DECL
+#define AB_MARK(i)
+#define AB_KEEP(x)
+#define AB_END
+#endif
+
 template <int NKB, bool PRO>
-__global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict__ x, const float* __restrict__ w_in,
-                                                         const float* __restrict__ b_in, const float* __restrict__ w_o,
+__global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict__ x, const float* __restrict__ wp_in,
+                                                         const float* __restrict__ b_in, const float* __restrict__ wp_o,
                                                          const float* __restrict__ b_o, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y1, SeqGeom g,
                                                          float scale_log2e, FfnPro pro) {
@@ -81,16 +154,32 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   const int64_t tok0 = seq_token_base(g, seq);
   const int tstride = seq_token_stride(g);
 
+  AB_DECL
+  // This head's W_k / W_v fragments, resident through phase 1.  The row-per-lane fragment loads (32 rows x 32 bytes per
+  // wave instruction) are expensive for the texture path and their round trip was 8.6 k exposed cycles per sequence in
+  // the phase stamps: with the prologue they are requested in front of its LAST 32-token block (peeled from the loop
+  // so that the 128 registers are not live through the others) and arrive behind its 128 MFMAs.
+  float wkf[64], wvf[64];
+  auto fetch_wkv = [&]() {
+    const float* wk = wp_in + ((1 * 4 + h) * 16 * 64 + lane) * 4;   // packed: [sel][head][m][lane][4]
+    const float* wv = wp_in + ((2 * 4 + h) * 16 * 64 + lane) * 4;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float4 a = ldg4(wk + m * 256), b = ldg4(wv + m * 256);
+      wkf[4 * m + 0] = a.x; wkf[4 * m + 1] = a.y; wkf[4 * m + 2] = a.z; wkf[4 * m + 3] = a.w;
+      wvf[4 * m + 0] = b.x; wvf[4 * m + 1] = b.y; wvf[4 * m + 2] = b.z; wvf[4 * m + 3] = b.w;
+    }
+  };
   if constexpr (PRO) {
     // ---- prologue: x rows = LN2(ReLU(h) W_f^T + b_f + y1_prev) of the previous path, block of 32 tokens at a time ----
     float* Hs = P;                           // [32][LDHC]  ReLU(h) rows of the block (A operand)
     float* Cs = P + 32 * LDHC;               // [32][LDP]   product tile on its way to row space
     float wff[128];                          // W_f[32h + c][8m + 4hh + t]: this wave's 32 output columns, K = 256
     {
-      const float* wr = pro.wf + (int64_t)(32 * h + c) * 256 + 4 * hh;
+      const float* wr = pro.wf + (h * 32 * 64 + lane) * 4;        // packed: [head][m][lane][4]
 #pragma unroll
       for (int m = 0; m < 32; ++m) {
-        const float4 t = ldg4(wr + 8 * m);
+        const float4 t = ldg4(wr + m * 256);
         wff[4 * m + 0] = t.x; wff[4 * m + 1] = t.y; wff[4 * m + 2] = t.z; wff[4 * m + 3] = t.w;
       }
 #pragma unroll
@@ -108,14 +197,16 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       }
     };
     fetch_h(0);
-    for (int rb = 0; rb < NKB; ++rb) {
+    AB_MARK(0)
+    auto pro_block = [&](int rb, bool more) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = i * 256 + tid;
         *reinterpret_cast<float4*>(&Hs[(idx >> 6) * LDHC + 4 * (idx & 63)]) = hst[i];
       }
       __syncthreads();
-      if (rb + 1 < NKB) fetch_h(rb + 1);
+      AB_MARK(1)
+      if (more) fetch_h(rb + 1);
       float4 res[4];                         // residual rows y1_prev of this thread's four row-space slots
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) res[pass] = ldg4(y1 + tok_of(rb * 32 + pass * 8 + prs) * N + 4 * pc4);
@@ -134,24 +225,29 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
           a1 = mfma32(af[m].w, wff[4 * (m0 + m) + 3], a1);
         }
       }
+      AB_KEEP(a0[15]) AB_KEEP(a1[15])
+      AB_MARK(2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) Cs[ROW32(r, hh) * LDP + 32 * h + c] = a0[r] + a1[r];
       __syncthreads();
+      AB_MARK(3)
+      {
+        float4 v[4];
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int row = pass * 8 + prs;
-        const float4 cv = *reinterpret_cast<const float4*>(&Cs[row * LDP + 4 * pc4]);
-        float4 v;
-        v.x = cv.x + bfc.x + res[pass].x; v.y = cv.y + bfc.y + res[pass].y;
-        v.z = cv.z + bfc.z + res[pass].z; v.w = cv.w + bfc.w + res[pass].w;
-        const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
-        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-        const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
-        const float rstd = rsqrtf(var + 1e-5f);
-        *reinterpret_cast<float4*>(&Xs[(rb * 32 + row) * LDX + 4 * pc4]) =
-            make_float4(dx * rstd * g2c.x + b2c.x, dy * rstd * g2c.y + b2c.y, dz * rstd * g2c.z + b2c.z, dw * rstd * g2c.w + b2c.w);
+        for (int pass = 0; pass < 4; ++pass) {
+          const float4 cv = *reinterpret_cast<const float4*>(&Cs[(pass * 8 + prs) * LDP + 4 * pc4]);
+          v[pass].x = cv.x + bfc.x + res[pass].x; v[pass].y = cv.y + bfc.y + res[pass].y;
+          v[pass].z = cv.z + bfc.z + res[pass].z; v[pass].w = cv.w + bfc.w + res[pass].w;
+        }
+        layernorm_rows_x4(v, g2c, b2c);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) *reinterpret_cast<float4*>(&Xs[(rb * 32 + pass * 8 + prs) * LDX + 4 * pc4]) = v[pass];
       }
-    }
+      AB_MARK(4)
+    };
+    for (int rb = 0; rb + 1 < NKB; ++rb) pro_block(rb, true);
+    fetch_wkv();
+    pro_block(NKB - 1, false);
   } else {
     // ---- stage the token rows: coalesced 512-byte rows -> LDS (every wave reads all of them as MFMA fragments) -----
     constexpr int NLD = NKB * 4;             // float4 per thread
@@ -161,24 +257,23 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       const int row = i * 8 + (tid >> 5);
       st[i] = ldg4(x + (tok0 + (int64_t)(row < len ? row : len - 1) * tstride) * N + 4 * (tid & 31));
     }
+    fetch_wkv();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(&Xs[(i * 8 + (tid >> 5)) * LDX + 4 * (tid & 31)]) = st[i];
   }
-  // ---- this head's weights, resident for the whole sequence: the row-per-lane fragment loads (32 rows x 32 bytes per
-  //      wave instruction) are expensive for the texture path, so they are issued once, not per token block ----------
-  float wkf[64], wvf[64];
+  __syncthreads();
+  AB_MARK(5)
+
+  // W_q fragments (A operand of the Q^T tiles, parked in AGPRs): requested here, they arrive behind phase 1
+  float wqf[64];
   {
-    const float* wk = w_in + (int64_t)(1 * N + h * DH + c) * N + 4 * hh;
-    const float* wv = w_in + (int64_t)(2 * N + h * DH + c) * N + 4 * hh;
+    const float* wq = wp_in + ((0 * 4 + h) * 16 * 64 + lane) * 4;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      const float4 a = ldg4(wk + 8 * m), b = ldg4(wv + 8 * m);
-      wkf[4 * m + 0] = a.x; wkf[4 * m + 1] = a.y; wkf[4 * m + 2] = a.z; wkf[4 * m + 3] = a.w;
-      wvf[4 * m + 0] = b.x; wvf[4 * m + 1] = b.y; wvf[4 * m + 2] = b.z; wvf[4 * m + 3] = b.w;
+      const float4 a = ldg4(wq + m * 256);
+      wqf[4 * m + 0] = a.x; wqf[4 * m + 1] = a.y; wqf[4 * m + 2] = a.z; wqf[4 * m + 3] = a.w;
     }
   }
-  __syncthreads();
-
   // ---- phase 1: K^T and V of this head for every key block, kept in registers --------------------------------
   f32x16 kt[NKB], vv[NKB];
   {
@@ -220,25 +315,17 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
     }
   }
 
+  AB_MARK(6)
   // ---- phase 2 constants: W_q fragments (A operand, parked in AGPRs), W_o slice of this head (B operand), biases ----
-  float wqf[64];
-  {
-    const float* wq = w_in + (int64_t)(0 * N + h * DH + c) * N + 4 * hh;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const float4 a = ldg4(wq + 8 * m);
-      wqf[4 * m + 0] = a.x; wqf[4 * m + 1] = a.y; wqf[4 * m + 2] = a.z; wqf[4 * m + 3] = a.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 64; ++i) asm volatile("" : "+a"(wqf[i]));
-  }
+  for (int i = 0; i < 64; ++i) asm volatile("" : "+a"(wqf[i]));
   float wof[4][16];                                              // W_o[32 jt + c][32 h + ROW32(r,hh)]
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
-    const float* wr = w_o + (int64_t)(32 * jt + c) * N + h * DH + 4 * hh;
+    const float* wr = wp_o + (((h * 4 + jt) * 4) * 64 + lane) * 4;   // packed: [head][jt][j][lane][4]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 t = ldg4(wr + 8 * j);
+      const float4 t = ldg4(wr + j * 256);
       wof[jt][4 * j + 0] = t.x; wof[jt][4 * j + 1] = t.y; wof[jt][4 * j + 2] = t.z; wof[jt][4 * j + 3] = t.w;
     }
   }
@@ -254,83 +341,149 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   float* Pw = P + h * 32 * LDP;
 
   // ---- phase 2: one query block at a time -----------------------------------------------------------------
-  for (int qb = 0; qb < NKB; ++qb) {
-    // Q^T tile, bias, scale by log2(e)/sqrt(dh)
-    f32x16 q;
-    {
-      const float* xr = &Xs[(qb * 32 + c) * LDX + 4 * hh];
-      f32x16 q0 = zero16(), q1 = zero16();
+  // Q^T tile of a block: 64 MFMAs in two chains (bias, scale by log2(e)/sqrt(dh) applied by the caller)
+  auto q_tile_mfmas = [&](int qb, f32x16& q0, f32x16& q1) {
+    const float* xr = &Xs[(qb * 32 + c) * LDX + 4 * hh];
 #pragma unroll
-      for (int m0 = 0; m0 < 16; m0 += 8) {
-        float4 xf[8];
+    for (int m0 = 0; m0 < 16; m0 += 8) {
+      float4 xf[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const float4*>(xr + 8 * (m0 + m));
+      for (int m = 0; m < 8; ++m) xf[m] = *reinterpret_cast<const float4*>(xr + 8 * (m0 + m));
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          q0 = mfma32(wqf[4 * (m0 + m) + 0], xf[m].x, q0);
-          q1 = mfma32(wqf[4 * (m0 + m) + 1], xf[m].y, q1);
-          q0 = mfma32(wqf[4 * (m0 + m) + 2], xf[m].z, q0);
-          q1 = mfma32(wqf[4 * (m0 + m) + 3], xf[m].w, q1);
-        }
+      for (int m = 0; m < 8; ++m) {
+        q0 = mfma32(wqf[4 * (m0 + m) + 0], xf[m].x, q0);
+        q1 = mfma32(wqf[4 * (m0 + m) + 1], xf[m].y, q1);
+        q0 = mfma32(wqf[4 * (m0 + m) + 2], xf[m].z, q0);
+        q1 = mfma32(wqf[4 * (m0 + m) + 3], xf[m].w, q1);
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) q[r] = (q0[r] + q1[r] + qbias[r]) * scale_log2e;
     }
+  };
+  // row-space epilogue of a block: y1 = LayerNorm(sum_h Y_h + b_o + x); a row = 32 adjacent lanes, 16 bytes per lane; the
+  // residual row comes from the staged tile
+  auto ln_epilogue = [&](int qb) {
+    float4 v[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 8 + rsub;
+      const float* pr = P + row * LDP + 4 * c4;
+      const float4 a0 = *reinterpret_cast<const float4*>(pr);
+      const float4 a1 = *reinterpret_cast<const float4*>(pr + 32 * LDP);
+      const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
+      const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
+      const float4 xres = *reinterpret_cast<const float4*>(&Xs[(qb * 32 + row) * LDX + 4 * c4]);
+      v[pass].x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres.x;
+      v[pass].y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres.y;
+      v[pass].z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres.z;
+      v[pass].w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres.w;
+    }
+    layernorm_rows_x4(v, ga, be);
+    // Straight-line on purpose (a branch per row would cut this region into basic blocks and nothing could be scheduled
+    // between the MFMAs next to it): padded rows p >= len carry the staged copy of row len-1 through the same
+    // arithmetic, so their result IS row len-1's, bit for bit, and is stored there once more.
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int p = qb * 32 + pass * 8 + rsub;
+      *reinterpret_cast<float4*>(y1 + (tok0 + (int64_t)(p < len ? p : len - 1) * tstride) * N + 4 * c4) = v[pass];
+    }
+  };
+  f32x16 qa = zero16(), qb_ = zero16();
+  q_tile_mfmas(0, qa, qb_);
+  AB_KEEP(qa[15]) AB_KEEP(qb_[15]) AB_KEEP(wof[3][15]) AB_KEEP(qbias[15]) AB_KEEP(bo.x) AB_KEEP(ga.x) AB_KEEP(be.x)
+  AB_MARK(7)
+  for (int qb = 0; qb < NKB; ++qb) {
+    f32x16 q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q[r] = (qa[r] + qb_[r] + qbias[r]) * scale_log2e;
     __builtin_amdgcn_sched_barrier(0);
-    // streaming softmax over the key blocks; O^T accumulated transposed (lane = query).  One wave per SIMD: the score
-    // tile of block kb+1 is computed between the MFMAs of O^T += V^T P^T of block kb (two independent chains).
+    // Streaming softmax over the key blocks; O^T accumulated transposed (lane = query).  One wave per SIMD, so nothing
+    // runs beside this wave: the loop is a two-stage pipeline in which iteration kb issues the MFMAs of
+    // O^T += V^T P^T of block kb-1 and of the score tile S^T of block kb+1 while the vector unit does the softmax of
+    // block kb (maximum, exp2, sum: ~100 instructions placed BETWEEN those MFMAs by the sched_group_barrier pattern;
+    // behind them they were ~400 cycles per block in which the matrix pipe idled).  The rescale of O^T by
+    // alpha(kb) waits until PV(kb-1) is in (end of the iteration; skipped, wave-uniformly, when no maximum moved).
     float mrun = -1e30f, lrun = 0.f;
     f32x16 o = zero16();
     f32x16 s = zero16();
 #pragma unroll
     for (int r = 0; r < 16; ++r) s = mfma32(kt[0][r], q[r], s);          // S^T[key ROW32(.,hh)][query c]
+    f32x16 pprev = zero16();
+    auto softmax_step = [&](auto KB) {
+      constexpr int kb = decltype(KB)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- matrix stream of this iteration
+      f32x16 snext = zero16();
+      if constexpr (kb > 0 && kb + 1 < NKB) {
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
+        for (int r = 0; r < 16; ++r) {
+          o = mfma32(vv[kb - 1][r], pprev[r], o);                         // O^T[d ROW32(.,hh)][query c]
+          snext = mfma32(kt[kb + 1][r], q[r], snext);
+        }
+      } else if constexpr (kb > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o = mfma32(vv[kb - 1][r], pprev[r], o);
+      } else if constexpr (kb + 1 < NKB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) snext = mfma32(kt[kb + 1][r], q[r], snext);
+      }
+      // ---- vector stream: softmax of block kb
       if (kb == NKB - 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kb * 32 + ROW32(r, hh) >= len) s[r] = -1e30f;
       }
-      float mx = s[0];
+      // (four partial maxima / sums: a 16-long dependent chain of v_max / v_add between the MFMAs stalls the in-order
+      //  issue behind it)
+      float m4[4] = {s[0], s[1], s[2], s[3]};
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = half_max(mx);
-      const float mnew = fmaxf(mrun, mx);
+      for (int r = 4; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], s[r]);
+      const float mx = half_max(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+      // Reference point of the exponentials: the running reference is kept while the block's maximum exceeds it by at
+      // most 2^8 (p <= 256: no overflow, fp32 accumulation) -- mathematically the same softmax, and the rescale of O^T
+      // (which has to wait for this iteration's PV MFMAs) becomes a rare event instead of one per block.
+      const float mnew = (kb == 0 || mx > mrun + 8.0f) ? mx : mrun;
       const float alpha = fast_exp2(mrun - mnew);
-      float sum = 0.f;
       f32x16 p;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         p[r] = fast_exp2(s[r] - mnew);
-        sum += p[r];
+        s4[r & 3] += p[r];
       }
-      sum = half_sum(sum);
+      const float sum = half_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
       lrun = lrun * alpha + sum;
+      // one MFMA, then a few vector instructions, ... (the groups are taken from this region in program order)
+      constexpr int NM = kb_mfmas(kb, NKB);
+      if constexpr (NM > 0) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (120 + NM - 1) / NM, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
       // the running maximum rarely moves after the first blocks: rescale O^T only if some query's did (wave-uniform)
       if (kb > 0 && __builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
       }
       mrun = mnew;
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb + 1 < NKB) {
-        s = zero16();
+      pprev = p;
+      s = snext;
+    };
+    static_for<NKB>(softmax_step);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          o = mfma32(vv[kb][r], p[r], o);                                 // O^T[d ROW32(.,hh)][query c]
-          s = mfma32(kt[kb + 1][r], q[r], s);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o = mfma32(vv[kb][r], p[r], o);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int r = 0; r < 16; ++r) o = mfma32(vv[NKB - 1][r], pprev[r], o);
     {
       const float inv = fast_rcp(lrun);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] *= inv;
     }
+    AB_KEEP(o[15])
+    AB_MARK(8)
+    // Every wave has long finished the epilogue of the previous block (it ran beside that block's successor's Q tile,
+    // a whole softmax loop ago): this barrier only makes that formal before the partial tiles are overwritten.
+    __syncthreads();
     // this head's share of the out-projection, two column tiles at a time (two chains): Y_h[query][32 jt + c]
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -348,38 +501,28 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    // row-space epilogue: y1 = LayerNorm(sum_h Y_h + b_o + x); a row = 32 adjacent lanes, 16 bytes per lane; the residual
-    // row comes from the staged tile
+    AB_MARK(9)
+    // The row-space epilogue of this block (LDS reads, ~300 vector instructions with two 32-lane reductions per row,
+    // the store) runs BETWEEN the 64 MFMAs of the next block's Q^T tile: neither depends on the other.
+    __builtin_amdgcn_sched_barrier(0);
+    if (qb + 1 < NKB) {
+      qa = zero16();
+      qb_ = zero16();
+      q_tile_mfmas(qb + 1, qa, qb_);
+      ln_epilogue(qb);
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int row = pass * 8 + rsub;
-      const int p = qb * 32 + row;
-      const float* pr = P + row * LDP + 4 * c4;
-      const float4 a0 = *reinterpret_cast<const float4*>(pr);
-      const float4 a1 = *reinterpret_cast<const float4*>(pr + 32 * LDP);
-      const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
-      const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
-      const float4 xres = *reinterpret_cast<const float4*>(&Xs[p * LDX + 4 * c4]);
-      float4 v;
-      v.x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres.x;
-      v.y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres.y;
-      v.z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres.z;
-      v.w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres.w;
-      const float mu = group_sum<32>((v.x + v.y) + (v.z + v.w)) * (1.0f / N);
-      const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-      const float var = group_sum<32>((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / N);
-      const float rstd = rsqrtf(var + 1e-5f);
-      if (p < len) {
-        float4 y;
-        y.x = dx * rstd * ga.x + be.x;
-        y.y = dy * rstd * ga.y + be.y;
-        y.z = dz * rstd * ga.z + be.z;
-        y.w = dw * rstd * ga.w + be.w;
-        *reinterpret_cast<float4*>(y1 + (tok0 + (int64_t)p * tstride) * N + 4 * c4) = y;
+      for (int i = 0; i < 64; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x1f6, 6, 0);     // up to six of: VALU, SALU, VMEM, DS
       }
+    } else {
+      ln_epilogue(qb);
     }
-    __syncthreads();   // the partial tiles are rewritten by the next query block
+    __builtin_amdgcn_sched_barrier(0);
+    AB_KEEP(qa[15]) AB_KEEP(qb_[15])
+    AB_MARK(10)
   }
+  AB_END
 }
 
 
@@ -656,18 +799,56 @@ __global__ __launch_bounds__(256) void attn_block_split_kernel(const float* __re
   }
 }
 
+// ---- weight packing (see attn_block.h) ---------------------------------------------------------------------------
+struct AttnPackArgs {
+  AttnPackSrc src[ATTN_PACK_MAX_PATHS];
+};
+__global__ __launch_bounds__(256) void attn_pack_kernel(AttnPackArgs a, float* __restrict__ dst) {
+  const int path = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;               // float4 index inside the path's pack
+  const AttnPackSrc s = a.src[path];
+  const int lane = f & 63, c = lane & 31, hh = lane >> 5;
+  const float* src;
+  if (f < ATTN_PACK_IN / 4) {                                  // [sel][head][m][lane]
+    const int m = (f >> 6) & 15, h = (f >> 10) & 3, sel = f >> 12;
+    src = s.w_in + (size_t)(sel * N + h * DH + c) * N + 8 * m + 4 * hh;
+  } else if (f < (ATTN_PACK_IN + ATTN_PACK_OUT) / 4) {         // [head][jt][j][lane]
+    const int g = f - ATTN_PACK_IN / 4;
+    const int j = (g >> 6) & 3, jt = (g >> 8) & 3, h = g >> 10;
+    src = s.w_o + (size_t)(32 * jt + c) * N + h * DH + 8 * j + 4 * hh;
+  } else {                                                     // [head][m][lane]
+    const int g = f - (ATTN_PACK_IN + ATTN_PACK_OUT) / 4;
+    const int m = (g >> 6) & 31, h = g >> 11;
+    src = s.w_f + (size_t)(32 * h + c) * 256 + 8 * m + 4 * hh;
+  }
+  *reinterpret_cast<float4*>(dst + (size_t)path * ATTN_PACK_FLOATS + 4 * (size_t)f) = *reinterpret_cast<const float4*>(src);
+}
+
 }  // namespace
+
+int attn_pack_launch(void* stream, const AttnPackSrc* src, int npaths, float* dst) {
+  static_assert(ATTN_PACK_FLOATS % 1024 == 0, "pack grid");
+  for (int p0 = 0; p0 < npaths; p0 += ATTN_PACK_MAX_PATHS) {
+    const int n = npaths - p0 < ATTN_PACK_MAX_PATHS ? npaths - p0 : ATTN_PACK_MAX_PATHS;
+    AttnPackArgs a{};
+    for (int i = 0; i < n; ++i) a.src[i] = src[p0 + i];
+    hipLaunchKernelGGL(attn_pack_kernel, dim3(ATTN_PACK_FLOATS / 1024, n), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       dst + (size_t)p0 * ATTN_PACK_FLOATS);
+  }
+  return (int)hipGetLastError();
+}
 
 size_t attn_block_lds_bytes(int nkb) { return sizeof(float) * ((size_t)nkb * 32 * LDX + 4 * 32 * LDP); }
 
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
-                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split, const AttnFfnPrologue* pro) {
+                      const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split, const AttnFfnPrologue* pro,
+                      const float* wpack) {
   using Kern = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                         SeqGeom, float, FfnPro);
   using KernS = void (*)(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                          SeqGeom, float);
   const int nkb = (g.len + 31) / 32;
-  if (nkb < 1 || nkb > 5 || (split && pro)) return (int)hipErrorInvalidValue;
+  if (nkb < 1 || nkb > 5 || (split && pro) || (!split && !wpack)) return (int)hipErrorInvalidValue;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
   const int dev = current_hip_device();
   if (split) {
@@ -710,7 +891,19 @@ int attn_block_launch(void* stream, const float* x, const float* w_in, const flo
   }
   FfnPro fp{};
   if (p) fp = FfnPro{pro->hc, pro->wf, pro->bf, pro->g2, pro->b2};
-  hipLaunchKernelGGL(kern, dim3(g.nseq), dim3(256), lds, static_cast<hipStream_t>(stream), x, w_in, b_in, w_o, b_o, gamma, beta, y1,
-                     g, scale_log2e, fp);
+  hipLaunchKernelGGL(kern, dim3(g.nseq), dim3(256), lds, static_cast<hipStream_t>(stream), x, wpack, b_in, wpack + ATTN_PACK_IN,
+                     b_o, gamma, beta, y1, g, scale_log2e, fp);
   return (int)hipGetLastError();
 }
+
+#ifdef ATTN_STAMPS
+// diagnostic build only (tools/attn_stamps.py): read / reset the phase sums
+extern "C" int dptnav_debug_attn_stamps(unsigned long long* out, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ab_stamps), z, sizeof(z));
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ab_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -37,7 +37,7 @@ constexpr int QUEUE_SLOTS = 1024;
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -50,6 +50,8 @@ struct Run {
   hipEvent_t lstm_wait = nullptr;    // if set: the recurrence launch waits for this event (other half's recurrence)
   hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
   int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
+  bool packed = false;               // ws + pl.wpack holds the packed weights of ALL paths (dptnav_forward); otherwise
+                                     // run_path packs the path it is about to run
   unsigned* take_queue(int n) {
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
     slot += n;
@@ -324,6 +326,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->hc = take(p->hc_n + (size_t)p->S * g.chunk_size * 2 * H);   // + dump rows for padded sequences
   p->stamps = take((size_t)2 * 2 * (nst_a > nst_e ? nst_a : nst_e) * 4 * 4 * 2);   // u64 [dir][tile][wave][4]
   p->wfold = take((size_t)8 * 2 * N + 8);   // folded decoder weights [G | W_dec^T | bd] (run_tail)
+  // fragment-order copies of the attention / FFN weights of every path for the fused attention block (attn_block.h)
+  p->wpack = take(g.arch == 0 && N == 128 ? (size_t)2 * g.num_blocks * ATTN_PACK_FLOATS : 0);
   p->total = o;
   return DPTNAV_OK;
 }
@@ -453,6 +457,19 @@ bool path_fusable(const dptnav_ctx* c, int path, int B, int S) {
   return c->cfg.arch == 0 && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && c->cfg.num_heads == 4;
 }
 
+// fragment-order copies of the attention / FFN weights of paths [first, first + n) for the fused attention block, from
+// the weights as they are NOW (an optimizer may have stepped since the last call)
+static int pack_attn_weights(dptnav_ctx* c, hipStream_t st, int first, int n, float* dst) {
+  std::vector<AttnPackSrc> src((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const PathWeights& w = c->pw[first + i];
+    src[(size_t)i] = AttnPackSrc{w.in_w, w.out_w, w.ffn_w};
+  }
+  const int rc = attn_pack_launch(st, src.data(), n, dst);
+  if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention weight pack: %s", hipGetErrorString((hipError_t)rc));
+  return DPTNAV_OK;
+}
+
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
              const PathBufs* bufs = nullptr, int chain = 0) {
@@ -482,8 +499,17 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       const PathWeights& pw = c->pw[2 * block + path - 1];
       pro = AttnFfnPrologue{hc, pw.ffn_w, pw.ffn_b, pw.ln2_w, pw.ln2_b};
     }
+    const float* wpack = nullptr;
+    if (!c->opt_split_bf16) {
+      float* pk = ws + pl.wpack + (size_t)(2 * block + path) * ATTN_PACK_FLOATS;
+      if (!run.packed) {   // stage entry points: this path only (dptnav_forward packs all paths in one launch)
+        if (int rc = pack_attn_weights(c, st, 2 * block + path, 1, pk)) return rc;
+      }
+      wpack = pk;
+      if (chain & CHAIN_PRO) pro.wf = pk - ATTN_PACK_FLOATS + ATTN_PACK_IN + ATTN_PACK_OUT;   // previous path's ffn.1 segment
+    }
     const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16,
-                                     (chain & CHAIN_PRO) ? &pro : nullptr);
+                                     (chain & CHAIN_PRO) ? &pro : nullptr, wpack);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention block: %s", hipGetErrorString((hipError_t)rc));
   } else if (chain & CHAIN_PRO) {
     return c->fail(DPTNAV_ERR_INVALID, "internal: FFN prologue requested for an unfused attention block");
@@ -1176,6 +1202,7 @@ int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st
   run->pl = pl;
   run->st = st;
   run->slot = 0;
+  run->packed = false;
   hipError_t e = hipMemsetAsync(ws + pl.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st);
   if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "ticket counter reset: %s", hipGetErrorString(e));
   return DPTNAV_OK;
@@ -1449,6 +1476,10 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
     int rc = big ? run_head<128>(h, run[i], mixi[i], e1i[i], e2i[i], Bs[i], T, Tv, E(i), X0(i))
                  : run_head<64>(h, run[i], mixi[i], e1i[i], e2i[i], Bs[i], T, Tv, E(i), X0(i));
     if (rc) return rc;
+    if (big && g.arch == 0 && h->opt_fuse_attn && !h->opt_split_bf16) {
+      if (int rc2 = pack_attn_weights(h, run[i].st, 0, 2 * g.num_blocks, run[i].ws + run[i].pl.wpack)) return rc2;
+      run[i].packed = true;
+    }
   }
   int prev = -1;
   for (int b = 0; b < g.num_blocks; ++b)
