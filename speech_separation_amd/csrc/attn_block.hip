@@ -182,31 +182,37 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
         const float4 t = ldg4(wr + m * 256);
         wff[4 * m + 0] = t.x; wff[4 * m + 1] = t.y; wff[4 * m + 2] = t.z; wff[4 * m + 3] = t.w;
       }
-#pragma unroll
-      for (int i = 0; i < 128; ++i) asm volatile("" : "+a"(wff[i]));
     }
     const int pc4 = tid & 31, prs = tid >> 5;
     const float4 bfc = ldg4(pro.bf + 4 * pc4), g2c = ldg4(pro.g2 + 4 * pc4), b2c = ldg4(pro.b2 + 4 * pc4);
     auto tok_of = [&](int row) { return tok0 + (int64_t)(row < len ? row : len - 1) * tstride; };
-    float4 hst[8];                           // the block's 32 x 256 floats: 8 x 16 bytes per thread, one block ahead
-    auto fetch_h = [&](int rb) {
+    // a block's 32 x 256 floats: 8 x 16 bytes per thread, fetched TWO blocks ahead (one block = ~10 k cycles was not
+    // always enough under load: the stamps showed ~1.4 k cycles per block in front of the staging stores)
+    float4 hst[2][8];
+    auto fetch_h = [&](int rb, float4* dst) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = i * 256 + tid;
-        hst[i] = ldg4(pro.hc + tok_of(rb * 32 + (idx >> 6)) * 256 + 4 * (idx & 63));
+        dst[i] = ldg4(pro.hc + tok_of(rb * 32 + (idx >> 6)) * 256 + 4 * (idx & 63));
       }
     };
-    fetch_h(0);
+    fetch_h(0, hst[0]);
+    if (NKB > 1) fetch_h(1, hst[1]);
+    // (the pin is a use: the W_f loads are waited for HERE, with the first rows already requested behind them)
+#pragma unroll
+    for (int i = 0; i < 128; ++i) asm volatile("" : "+a"(wff[i]));
     AB_MARK(0)
-    auto pro_block = [&](int rb, bool more) {
+    auto pro_block = [&](auto RB) {
+      constexpr int rb = decltype(RB)::value;
+      if constexpr (rb == NKB - 1) fetch_wkv();
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int idx = i * 256 + tid;
-        *reinterpret_cast<float4*>(&Hs[(idx >> 6) * LDHC + 4 * (idx & 63)]) = hst[i];
+        *reinterpret_cast<float4*>(&Hs[(idx >> 6) * LDHC + 4 * (idx & 63)]) = hst[rb & 1][i];
       }
       __syncthreads();
       AB_MARK(1)
-      if (more) fetch_h(rb + 1);
+      if constexpr (rb + 2 < NKB) fetch_h(rb + 2, hst[rb & 1]);
       float4 res[4];                         // residual rows y1_prev of this thread's four row-space slots
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) res[pass] = ldg4(y1 + tok_of(rb * 32 + pass * 8 + prs) * N + 4 * pc4);
@@ -245,9 +251,7 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       }
       AB_MARK(4)
     };
-    for (int rb = 0; rb + 1 < NKB; ++rb) pro_block(rb, true);
-    fetch_wkv();
-    pro_block(NKB - 1, false);
+    static_for<NKB>(pro_block);
   } else {
     // ---- stage the token rows: coalesced 512-byte rows -> LDS (every wave reads all of them as MFMA fragments) -----
     constexpr int NLD = NKB * 4;             // float4 per thread
