@@ -104,7 +104,7 @@ int main() {
     float* W6;
     hipMalloc(&W6, 128 * 256 * 4);
     hipMemset(W6, 0, 128 * 256 * 4);
-    ALoadCols al{HC, M, 256, 0, 32, false};
+    ALoadCols al{HC, M, 256, 0, 32};
     EpiBiasResLN<32> ep{Y, bias, X, gam, bet, M, N, 32};
     auto kern = gemm_ws_kernel<256, 1, 1, 4, ALoadCols, EpiBiasResLN<32>, false>;
     const size_t lds = GemmShape<256, 1, 1, 4>::lds_bytes(false);
