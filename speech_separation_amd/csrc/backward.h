@@ -117,17 +117,6 @@ struct WgradShape {
 // grid.x workgroups; slab[blockIdx.x][NN][KK] receives the partial sum of this workgroup's tiles.
 constexpr int wgrad_gcd(int a, int b) { return b == 0 ? a : wgrad_gcd(b, a % b); }
 
-// operand fetch of the weight-gradient kernels: the loader's branch-free zero-filling form where it has one
-template <class L, class = void>
-struct has_load4z : std::false_type {};
-template <class L>
-struct has_load4z<L, std::void_t<decltype(std::declval<const L&>().load4z(0, 0, 0))>> : std::true_type {};
-template <class L>
-DEV float4 wg_load(const L& l, int tile, int row, int k4) {
-  if constexpr (has_load4z<L>::value) return l.load4z(tile, row, k4);
-  else return l.load4(tile, row, k4);
-}
-
 // COLSUM: the column sums of Y (= the bias gradient of the same layer) ride along: every thread adds up the float4s it
 // stages (their column is the same for every tile), the workgroup combines them in a fixed order at the end into
 // colslab[blockIdx.x][NN] -- instead of a second pass over Y by colsum_kernel.

@@ -81,6 +81,7 @@ struct dptnav_ctx {
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
+  bool opt_wgrad_ride = true;       // training: out-projection / ffn weight gradients formed inside their data-gradient GEMMs
   bool opt_wgrad2 = true;           // training: LSTM W_ih / W_hh gradients in one pass over dP (wgrad2_kernel)
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
@@ -392,17 +393,22 @@ int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeo
 }
 
 // ---- generic GEMM-engine launch -------------------------------------------------------------------
+constexpr int BWD_SLAB_WGS = 256;       // workgroups of one wgrad / colsum launch (one partial slab each)
+
 // The engine is persistent (grid-stride over tiles, weights loaded once per workgroup), so the grid is
 // sized to what is co-resident: CUs x blocks/CU from the occupancy query, queried once per instantiation.
-template <int KIN, int NT, int WR, int WC, bool WT = false, bool SPLIT = false, class AL, class EP>
+// RD = WgradRider<...> (gemm_ws.h): the launch also forms the weight gradient of the layer whose data gradient it is;
+// one workgroup per CU then (as many partial tiles as the stand-alone weight-gradient kernels leave), grid in *grid_used.
+template <int KIN, int NT, int WR, int WC, bool WT = false, bool SPLIT = false, class AL, class EP, class RD = NoRider>
 int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float* W, int64_t ntiles, int colgroups,
-                const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr) {
+                const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr,
+                const RD& rider = RD{}) {
   hipStream_t st = run.st;
   if (c->opt_inject_fail > 0 && --c->opt_inject_fail == 0)   // fault injection for the error-path tests (option "inject_fail")
     return c->fail(DPTNAV_ERR_INVALID, "%s: injected failure", what);
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
-  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT, SPLIT>;
-  const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT, SPLIT);
+  auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT, SPLIT, RD>;
+  const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT, SPLIT, rider_kk<RD>::value * (RD::ON ? 1 : 0));
   static std::atomic<int> resident_dev[64];  // per instantiation and device (zero-initialised; idempotent fill)
   int resident = resident_dev[c->device_id & 63].load(std::memory_order_acquire);
   if (resident == 0) {
@@ -412,7 +418,8 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
     if (e != hipSuccess || per_cu < 1) return c->fail(DPTNAV_ERR_HIP, "%s: occupancy query: %s", what, hipGetErrorString(e));
     // two workgroups per CU cover each other's barriers; a third only adds a weight-load prologue per launch
     // (out-projection GEMM: 0.157 ms with 512 workgroups, 0.160 with 768)
-    resident = std::min(per_cu, 2) * c->num_cus;
+    resident = (RD::ON ? 1 : std::min(per_cu, 2)) * c->num_cus;
+    if (RD::ON && resident > BWD_SLAB_WGS) resident = BWD_SLAB_WGS;   // one partial tile per workgroup in the slab region
     resident_dev[c->device_id & 63].store(resident, std::memory_order_release);
   }
   int gx = resident / colgroups;
@@ -420,7 +427,7 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
   ProfScope ps(c, cat, st);
   if (grid_used) *grid_used = cap_grid(ntiles, gx);
   hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, ldw, (int)ntiles,
-                     run.take_queue(colgroups), al, ep);
+                     run.take_queue(colgroups), al, ep, rider);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -716,7 +723,6 @@ struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
   int slab_wgs;
 };
-constexpr int BWD_SLAB_WGS = 256;       // workgroups of one wgrad / colsum launch (one partial slab each)
 constexpr int BWD_LNP_WGS = 2048;       // upper bound of GEMM-engine workgroups writing LayerNorm partials
 
 int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
@@ -817,6 +823,20 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
   return DPTNAV_OK;
 }
 
+// sums of the partial tiles / column sums a WgradRider launch (launch_gemm) left in the slab region
+template <int NN, int KK>
+int reduce_rider(dptnav_ctx* c, BwdRun& br, const char* what, int grid, int col_after, float* grad, float* bias_grad) {
+  constexpr int64_t count = (int64_t)NN * KK;
+  float* slab = br.ws + br.pl.slab;
+  float* colslab = slab + (size_t)col_after * count;   // where the launch put its column-sum rows
+  FragOuts outs{};
+  outs.out[0] = grad;
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128) + (bias_grad ? (NN + 31) / 32 : 0)),
+                     dim3(256), 0, br.st, slab, grid, count, outs, (int64_t)0, 1, colslab, bias_grad ? NN : 0, bias_grad);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
 // NSL pairs of gradients, each pair sharing its Y operand, in one pass and ONE launch (wgrad2_kernel):
 // gradA[s] = sum Y_s^T Xa_s, gradB[s] = sum Y_s^T Xb_s
 template <int NN, int KK, int NSL, class YL, class XA, class XB>
@@ -903,22 +923,39 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     LAUNCH_CHECK(c, "ln2 grads");
   }
   br.slot = run.slot;
-  // 2. ffn parameter gradients
-  {
-    ALoadCols yl{DZ, M, N, 0, 32};
-    ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
-    if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
-      return rc;
-  }
-  // 3. d h = (dz2 W_f) masked by the ReLU
-  run.slot = br.slot;
-  {
+  // 2 + 3. ffn parameter gradients and d h = (dz2 W_f) masked by the ReLU.  Option wgrad_ride (default): ONE launch -- the
+  //        data-gradient GEMM stages the dz2 tile anyway and forms dW_f / db_f on the side (WgradRider, gemm_ws.h)
+  if (c->opt_wgrad_ride) {
+    run.slot = br.slot;
     ALoadDense al{DZ, M, N, 32};
     EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
-    if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
+    float* slab = br.ws + br.pl.slab;
+    int rgrid = 0;
+    // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
+    WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
+                                                   slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
+    if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
+                                                      2 * LSTM_H, &rgrid, rd))
       return rc;
+    br.slot = run.slot;
+    if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
+      return rc;
+  } else {
+    {
+      ALoadCols yl{DZ, M, N, 0, 32};
+      ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
+      if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
+        return rc;
+    }
+    run.slot = br.slot;
+    {
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+      if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
+        return rc;
+    }
+    br.slot = run.slot;
   }
-  br.slot = run.slot;
   // 4. LSTM backward through time (tile height as in the forward that wrote the tape)
   const bool use16 = lstm_use16(c, geom, 2, M);
   const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;   // workgroups per direction = partial bias rows
@@ -983,21 +1020,36 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     LAUNCH_CHECK(c, "ln1 grads");
   }
   br.slot = run.slot;
-  // 8. out-projection gradients and d att
-  {
-    ALoadCols yl{DZ, M, N, 0, 32};
-    ALoadDense xl{att, M, N, 32};
-    if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
-                                    G("mha.out_proj.bias")))
-      return rc;
-  }
-  run.slot = br.slot;
-  {
+  // 8. out-projection gradients and d att (one launch with option wgrad_ride, as in 2 + 3)
+  if (c->opt_wgrad_ride) {
+    run.slot = br.slot;
     ALoadDense al{DZ, M, N, 32};
     EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
-    if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+    float* slab = br.ws + br.pl.slab;
+    int rgrid = 0;
+    WgradRider<N, ALoadDense, true> rd{ALoadDense{att, M, N, 32}, slab, slab + (size_t)BWD_SLAB_WGS * N * N, M};
+    if (int rc = launch_gemm<N, 1, 1, 4, true, false>(c, run, CAT_OUTPROJ, "d att + d out weight", w.out_w, ntiles, 1, al, ep,
+                                                      nullptr, N, &rgrid, rd))
+      return rc;
+    br.slot = run.slot;
+    if (int rc = reduce_rider<N, N>(c, br, "d out weight + bias", rgrid, BWD_SLAB_WGS, G("mha.out_proj.weight"), G("mha.out_proj.bias")))
+      return rc;
+  } else {
+    {
+      ALoadCols yl{DZ, M, N, 0, 32};
+      ALoadDense xl{att, M, N, 32};
+      if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
+                                      G("mha.out_proj.bias")))
+        return rc;
+    }
+    run.slot = br.slot;
+    {
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
+      if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+    }
+    br.slot = run.slot;
   }
-  br.slot = run.slot;
   // 9. attention backward
   {
     const int nkb = (geom.len + 31) / 32;
@@ -1946,6 +1998,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "fold_tail") h->opt_fold_tail = value != 0;
+  else if (k == "wgrad_ride") h->opt_wgrad_ride = value != 0;
   else if (k == "sub_batches" && value >= 0 && value <= MAX_SUB) h->opt_sub_batches = value;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;

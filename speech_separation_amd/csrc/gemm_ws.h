@@ -75,6 +75,89 @@ template <class T>
 struct has_prefetchc<T, std::void_t<decltype(std::declval<const T&>().prefetchc(0, 0, 0))>> : std::true_type {};
 struct EpiColsFallback { using Cols = EpiNoCols; };
 
+// operand fetch of the weight-gradient code: the loader's branch-free zero-filling form where it has one
+template <class L, class = void>
+struct has_load4z : std::false_type {};
+template <class L>
+struct has_load4z<L, std::void_t<decltype(std::declval<const L&>().load4z(0, 0, 0))>> : std::true_type {};
+template <class L>
+DEV float4 wg_load(const L& l, int tile, int row, int k4) {
+  if constexpr (has_load4z<L>::value) return l.load4z(tile, row, k4);
+  else return l.load4(tile, row, k4);
+}
+
+// RIDER: a data-gradient GEMM  dX = dY W  stages the very tile of dY that the weight gradient of the same layer,
+// dW[KIN][KK] = sum_tokens dY^T X  (+ db = column sums of dY), needs as its A operand.  With a rider the kernel also
+// stages the X tile, runs the 16 x (KIN/128) x (KK/32) MFMAs of the weight gradient per tile on accumulators that live
+// through the whole launch, and leaves one partial dW per workgroup (fragment order, slab_reduce_frag_kernel) -- instead
+// of a second kernel (wgrad_kernel) that reads dY again and pays its own staging, barriers, tickets and store tail.
+// Rows >= M: the X loader zero-fills (the engine's A loader clamps), the column sums skip them.
+struct NoRider {
+  static constexpr bool ON = false;
+};
+template <class R, class = void>
+struct rider_kk : std::integral_constant<int, 32> {};
+template <class R>
+struct rider_kk<R, std::enable_if_t<R::ON>> : std::integral_constant<int, R::KK> {};
+template <class R, class = void>
+struct rider_colsum : std::false_type {};
+template <class R>
+struct rider_colsum<R, std::enable_if_t<R::ON>> : std::integral_constant<bool, R::COLSUM> {};
+template <int KK_, class XLoad, bool COLSUM_>
+struct WgradRider {
+  static constexpr bool ON = true;
+  static constexpr int KK = KK_;
+  static constexpr bool COLSUM = COLSUM_;
+  XLoad xl;
+  float* slab;      // [gridDim.x][KIN * KK] partial tiles, fragment order
+  float* colslab;   // [gridDim.x][KIN] partial column sums of dY (COLSUM)
+  int64_t M;
+};
+
+template <class R>
+DEV float4 rider_load(const R& r, int tile, int row, int k4) {
+  if constexpr (R::ON) return wg_load(r.xl, tile, row, k4);
+  else return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <class R>
+DEV int64_t rider_rows(const R& r) {
+  if constexpr (R::ON) return r.M;
+  else return 0;
+}
+
+// partial dW of this workgroup in fragment order (wgrad_kernel's layout: slab_reduce_frag_kernel<RB, CB>), and the
+// partial column sums: a thread's accumulator belongs to column block tid % (KIN/4); owner thread cb < KIN/4 sums its
+// contributors in tid order (fixed association order)
+template <int KIN, int RB, int CB, bool CS, class R, class Acc>
+DEV void rider_finish(const R& r, Acc& racc, float4 rcsum, float* smem, int tid, int wave, int lane) {
+  if constexpr (R::ON) {
+    float* out = r.slab + (size_t)blockIdx.x * (KIN * CB * 32);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(out + ((((size_t)(wave * RB + i) * CB + j) * 4 + g4) * 64 + lane) * 4) =
+              make_float4(racc[i][j][4 * g4], racc[i][j][4 * g4 + 1], racc[i][j][4 * g4 + 2], racc[i][j][4 * g4 + 3]);
+    if constexpr (CS) {
+      constexpr int Y4 = KIN / 4;
+      __syncthreads();
+      float4* red = reinterpret_cast<float4*>(smem);
+      red[tid] = rcsum;
+      __syncthreads();
+      if (tid < Y4) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t2 = tid; t2 < 256; t2 += Y4) {
+          const float4 u = red[t2];
+          a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+        *reinterpret_cast<float4*>(r.colslab + (size_t)blockIdx.x * KIN + 4 * tid) = a;
+      }
+    }
+  }
+}
+
 template <int KIN, int NT, int WR, int WC>
 struct GemmShape {
   static constexpr int BM = 32 * WR;
@@ -83,9 +166,10 @@ struct GemmShape {
   static constexpr int LDC = WGCOLS + 4;
   static constexpr int KS = KIN / 2;       // MFMA k-steps
   static constexpr int LDAB = KIN + 8;     // split mode: bf16 rows (hi and lo images), conflict-free ds_read_b128
-  static constexpr size_t lds_bytes(bool direct, bool split = false) {
+  static constexpr size_t lds_bytes(bool direct, bool split = false, int rider_kk = 0) {
     // split mode: the double-buffered A tile is two bf16 images (hi, lo) instead of one fp32 image
-    return sizeof(float) * (4 + (split ? 2 * (size_t)BM * LDAB : 2 * (size_t)BM * LDA) + (direct ? 0 : (size_t)BM * LDC));
+    return sizeof(float) * (4 + (split ? 2 * (size_t)BM * LDAB : 2 * (size_t)BM * LDA) + (direct ? 0 : (size_t)BM * LDC) +
+                            (rider_kk ? 2 * 32 * (size_t)(rider_kk + 4) : 0));
   }
 };
 
@@ -95,16 +179,21 @@ struct GemmShape {
 // operands split into bf16 hi + lo -- A while it is staged to LDS, W while it is loaded into registers (same register
 // bytes) -- as hi*hi + hi*lo + lo*hi with fp32 accumulation: 24 bf16 MFMAs of 32 cycles replace 64 fp32 ones of 64 per
 // 32x32x128 block.  Accumulator layout, loaders and epilogues are shared with the fp32 form.
-template <int KIN, int NT, int WR, int WC, class ALoad, class Epi, bool WT = false, bool SPLIT = false>
+template <int KIN, int NT, int WR, int WC, class ALoad, class Epi, bool WT = false, bool SPLIT = false, class Rider = NoRider>
 __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ W,
                                                        const float* __restrict__ Walt, int ldw, int ntiles,
-                                                       unsigned* __restrict__ tile_queue, ALoad aload, Epi epi) {
+                                                       unsigned* __restrict__ tile_queue, ALoad aload, Epi epi,
+                                                       Rider rider = Rider{}) {
   using Sh = GemmShape<KIN, NT, WR, WC>;
   static_assert(WR * WC == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_next = reinterpret_cast<int*>(smem);       // [2] tile tickets (double buffered), 16-byte slot
   float* As = smem + 4;
   float* Cs = As + (SPLIT ? 2 * Sh::BM * Sh::LDAB : 2 * Sh::BM * Sh::LDA);
+  // RIDER: X tiles [2][32][KK + 4] behind the C tile
+  constexpr int RKK = rider_kk<Rider>::value, LDXR = RKK + 4;
+  float* Xr = Cs + (Epi::DIRECT ? 0 : Sh::BM * Sh::LDC);
+  static_assert(!Rider::ON || (!SPLIT && WR == 1 && WC == 4 && KIN % 128 == 0 && RKK % 32 == 0), "rider shape");
   __bf16* Ahi = reinterpret_cast<__bf16*>(As);                 // SPLIT: [2][BM][LDAB] hi image, then the lo image
   __bf16* Alo = Ahi + 2 * Sh::BM * Sh::LDAB;
   static_assert(!(SPLIT && WT), "split mode: forward weight layout only");
@@ -198,6 +287,19 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   }
   __syncthreads();
   float4 pf[NLD];
+  // RIDER state: the weight-gradient accumulators of this workgroup (whole launch), the staged X rows, column sums of dY
+  constexpr int RRB = KIN / 128, RCB = RKK / 32, RX4 = RKK / 4, RNX = Rider::ON ? (32 * RX4) / 256 : 1;
+  constexpr bool RCS = rider_colsum<Rider>::value;
+  static_assert(!RCS || 256 % K4 == 0, "rider column sums: a thread's staging slots share their column block");
+  f32x16 racc[Rider::ON ? RRB : 1][Rider::ON ? RCB : 1];
+  float4 px[RNX];
+  float4 rcsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (Rider::ON) {
+#pragma unroll
+    for (int a = 0; a < RRB; ++a)
+#pragma unroll
+      for (int b = 0; b < RCB; ++b) racc[a][b] = zero16();
+  }
   int tile = __builtin_amdgcn_readfirstlane(s_next[0]);
   auto load_tile = [&](int t) {
 #pragma unroll
@@ -205,6 +307,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       const int idx = i * 256 + tid;
       if constexpr (has_load4c<ALoad>::value) pf[i] = aload.load4c(t, idx / K4, idx % K4);
       else pf[i] = aload.load4(t, idx / K4, idx % K4);
+    }
+    if constexpr (Rider::ON) {
+#pragma unroll
+      for (int i = 0; i < RNX; ++i) {
+        const int idx = i * 256 + tid;
+        px[i] = rider_load(rider, t, idx / RX4, idx % RX4);
+      }
     }
   };
   if (tile < ntiles) load_tile(tile);
@@ -231,6 +340,19 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         *reinterpret_cast<bf16x4*>(&Alo[off]) = l4;
       } else {
         *reinterpret_cast<float4*>(&Ab[(idx / K4) * Sh::LDA + 4 * (idx % K4)]) = pf[i];
+      }
+      if constexpr (RCS) {   // db: rows beyond M are clamped copies here and must not count
+        if ((int64_t)tile * Sh::BM + idx / K4 < rider_rows(rider)) {
+          rcsum.x += pf[i].x; rcsum.y += pf[i].y; rcsum.z += pf[i].z; rcsum.w += pf[i].w;
+        }
+      }
+    }
+    if constexpr (Rider::ON) {
+      float* Xb = Xr + buf * (32 * LDXR);
+#pragma unroll
+      for (int i = 0; i < RNX; ++i) {
+        const int idx = i * 256 + tid;
+        *reinterpret_cast<float4*>(&Xb[(idx / RX4) * LDXR + 4 * (idx % RX4)]) = px[i];
       }
     }
     GEMM_STAMP(0);     // (diagnostic builds: phase 0 = ticket + A tile -> LDS, phase 1 = the barrier)
@@ -320,6 +442,24 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       }
     }
 
+    if constexpr (Rider::ON) {
+      // dW += dY_tile^T X_tile: MFMA step s takes tokens (2s, 2s+1) as its two k-slots; wave w owns rows (w + 4 i) * 32 of dW
+      const float* Xb = Xr + buf * (32 * LDXR);
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float* yrow = Ab + (2 * s2 + hh) * Sh::LDA + c;
+        const float* xrow = Xb + (2 * s2 + hh) * LDXR + c;
+        float ra[RRB], rb[RCB];
+#pragma unroll
+        for (int i = 0; i < RRB; ++i) ra[i] = yrow[(wave + 4 * i) * 32];
+#pragma unroll
+        for (int j = 0; j < RCB; ++j) rb[j] = xrow[j * 32];
+#pragma unroll
+        for (int i = 0; i < RRB; ++i)
+#pragma unroll
+          for (int j = 0; j < RCB; ++j) racc[i][j] = mfma32(ra[i], rb[j], racc[i][j]);
+      }
+    }
     // Keep epilogue arithmetic on the prefetched operands (bias + residual ...) behind the MFMA block: scheduled in
     // front of it, it waited (s_waitcnt vmcnt(0)) for loads issued a moment earlier.  The empty asm makes the operands
     // "produced" here; plain arithmetic is not ordered by sched_barrier at instruction selection.
@@ -367,6 +507,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   }
   GEMM_STAMP_END
   if constexpr (Epi::HAS_FINISH) epi.finish(smem, tid);   // e.g. per-workgroup partial sums of parameter gradients
+  if constexpr (Rider::ON) rider_finish<KIN, RRB, RCB, RCS>(rider, racc, rcsum, smem, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
