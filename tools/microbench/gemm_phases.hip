@@ -54,7 +54,7 @@ void run(const char* name, Kern kern, size_t lds, int wgs, int ntiles, const flo
     hipMemset(queue, 0, 64);
     hipMemset(seg, 0, (size_t)wgs * 4 * 8 * 8);
     hipEventRecord(a);
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, 0, W, (const float*)nullptr, ldw, ntiles, queue, al, ep);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, 0, W, (const float*)nullptr, ldw, ntiles, queue, al, ep, NoRider{});
     hipEventRecord(b);
     hipDeviceSynchronize();
     hipEventElapsedTime(&ms, a, b);
