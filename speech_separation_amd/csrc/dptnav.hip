@@ -101,6 +101,8 @@ struct dptnav_ctx {
   static constexpr int NSTREAMS = 4;   // internal streams (dptnav_forward uses min(sub-batches, NSTREAMS); training two)
   hipStream_t streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
+  hipEvent_t ev_side[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // side streams of the training backward
+  bool opt_wgrad_side = true;       // training, split batches: LSTM weight gradients on a side stream per half
   int opt_sub_batches = 0;          // 0: forward_split decides; n > 0: that many sub-batches (experiments)
   std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
   int ensure_sub_events(int n) {
@@ -113,6 +115,12 @@ struct dptnav_ctx {
   }
   int ensure_streams() {
     if (streams[0]) return 0;
+    for (int i = 0; i < 2; ++i)
+      for (int k = 0; k < 3; ++k)
+        if (hipEventCreateWithFlags(&ev_side[i][k], hipEventDisableTiming) != hipSuccess) {
+          err = "cannot create internal streams/events";
+          return 4;
+        }
     for (int i = 0; i < NSTREAMS; ++i) {
       if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess ||
@@ -721,6 +729,7 @@ struct PathTape {  // offsets in floats inside one path's tape
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
+  size_t dg2, slab2, queue2;   // second dP buffer / slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
   int slab_wgs;
 };
 constexpr int BWD_LNP_WGS = 2048;       // upper bound of GEMM-engine workgroups writing LayerNorm partials
@@ -758,6 +767,9 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv
   p->datt = take((size_t)M * N);
   p->dqkv = take((size_t)M * 3 * N);
   p->slab = take((size_t)BWD_SLAB_WGS * 512 * 128);
+  p->dg2 = take((size_t)MD * 2 * 4 * H);
+  p->slab2 = take((size_t)BWD_SLAB_WGS * 512 * 128);
+  p->queue2 = take(QUEUE_SLOTS);
   p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
   p->dxa = take((size_t)M * N);                     // gradient ping-pong between paths
   p->dxb = take((size_t)M * N);
@@ -780,6 +792,19 @@ struct BwdRun {
   int half = 0;
   hipEvent_t lstm_wait = nullptr;    // BPTT launches of the two halves of a split batch are chained like the forward's
   hipEvent_t lstm_record = nullptr;
+  // Side stream (option wgrad_side, split batches): nothing needs dW before the step ends, so the LSTM weight-gradient
+  // launches leave the half's chain and run whenever CUs are free -- in particular while this half waits for the other
+  // half's BPTT (8.9 ms per step with 114 CUs idle in the kernel timeline).  dP alternates between two buffers: the BPTT
+  // of path p-2 waits for the weight gradients of path p to have read theirs.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_bptt = nullptr, ev_wg[2] = {nullptr, nullptr};
+  bool wg_pending[2] = {false, false};
+  int dg_sel = 0, side_slot = 0;
+  unsigned* take_queue_side(int n) {   // own counters: the main stream re-zeroes its region while side launches may be in flight
+    unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue2) + side_slot;
+    side_slot += n;
+    return q;
+  }
   unsigned* take_queue(int n) {
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
     slot += n;
@@ -841,13 +866,13 @@ int reduce_rider(dptnav_ctx* c, BwdRun& br, const char* what, int grid, int col_
 // gradA[s] = sum Y_s^T Xa_s, gradB[s] = sum Y_s^T Xb_s
 template <int NN, int KK, int NSL, class YL, class XA, class XB>
 int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const Wgrad2Args<YL, XA, XB, NSL>& args,
-                  float* const* gradA, float* const* gradB) {
+                  float* const* gradA, float* const* gradB, hipStream_t wst, float* slab, unsigned* queue) {
   const size_t lds = sizeof(float) * (4 + 32 * (size_t)(WgradShape<NN, KK>::LDY + 2 * WgradShape<NN, KK>::LDX));
   static_assert(2 * NSL <= 8, "FragOuts");
   int grid = cap_grid(ntiles * NSL, br.pl.slab_wgs);
   grid -= grid % NSL;                          // the same number of workgroups for every slice
   if (grid < NSL) grid = NSL;
-  float* slab = br.ws + br.pl.slab;            // [NSL][grid / NSL][2][NN][KK]: BWD_SLAB_WGS x 512 x 128 floats hold <256,128> exactly
+  // slab: [NSL][grid / NSL][2][NN][KK]: BWD_SLAB_WGS x 512 x 128 floats hold <256,128> exactly
   static_assert(2 * NN * KK <= 512 * 128, "slab size");
   auto kern = wgrad2_kernel<NN, KK, YL, XA, XB, NSL>;
   static PerDeviceOnce ready;
@@ -855,7 +880,7 @@ int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, c
     if (int rc = set_lds(c, kern, lds, what)) return rc;
     ready.set(c->device_id);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(NSL), args, slab);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, wst, (int)ntiles, queue, args, slab);
   LAUNCH_CHECK(c, what);
   constexpr int64_t count = (int64_t)NN * KK;
   FragOuts outs{};
@@ -864,7 +889,7 @@ int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, c
     outs.out[2 * s + 1] = gradB[s];
   }
   // sum y = (slice, a / b): the slabs of a slice are 2 * count apart, a slice's region is (grid / NSL) of them
-  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128), 2 * NSL), dim3(256), 0, br.st, slab,
+  hipLaunchKernelGGL((slab_reduce_frag_kernel<NN / 128, KK / 32>), dim3((unsigned)(count / 128), 2 * NSL), dim3(256), 0, wst, slab,
                      grid / NSL, 2 * count, outs, (int64_t)(grid / NSL) * 2 * count, 2, (const float*)nullptr, 0, (float*)nullptr);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
@@ -960,6 +985,12 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   const bool use16 = lstm_use16(c, geom, 2, M);
   const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;   // workgroups per direction = partial bias rows
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
+  const bool side = br.side != nullptr && c->opt_wgrad2;
+  if (side) {   // this path's dP goes to the buffer the weight gradients of two paths ago have (or will have) read
+    if (br.dg_sel) DG = br.ws + br.pl.dg2;
+    if (br.wg_pending[br.dg_sel] && hipStreamWaitEvent(st, br.ev_wg[br.dg_sel], 0) != hipSuccess)
+      return c->fail(DPTNAV_ERR_HIP, "side stream wait");
+  }
   {
     ProfScope ps(c, CAT_LSTM, st);
     const int rc = use16 ? lstm_bptt16_launch(ntl, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M,
@@ -998,8 +1029,21 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       }
     }
   }
-  if (c->opt_wgrad2)
-    if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB)) return rc;
+  if (c->opt_wgrad2) {
+    if (side) {
+      if (hipEventRecord(br.ev_bptt, st) != hipSuccess || hipStreamWaitEvent(br.side, br.ev_bptt, 0) != hipSuccess)
+        return c->fail(DPTNAV_ERR_HIP, "side stream fork");
+      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, br.side, br.ws + br.pl.slab2,
+                                           br.take_queue_side(4)))
+        return rc;
+      if (hipEventRecord(br.ev_wg[br.dg_sel], br.side) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream record");
+      br.wg_pending[br.dg_sel] = true;
+      br.dg_sel ^= 1;
+    } else {
+      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, br.take_queue(4)))
+        return rc;
+    }
+  }
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
   run.slot = br.slot;
   for (int d = 0; d < 2; ++d) {
@@ -1336,6 +1380,9 @@ void dptnav_destroy(dptnav_handle h) {
   }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (hipEvent_t e : h->ev_sub) hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i)
+    for (int k = 0; k < 3; ++k)
+      if (h->ev_side[i][k]) hipEventDestroy(h->ev_side[i][k]);
   delete h;
 }
 
@@ -1916,6 +1963,14 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
     br[i].half = i;
     if (hipMemsetAsync(br[i].ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), si[i]) != hipSuccess)
       return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+    if (sp.nhalf == 2 && h->opt_wgrad_side) {
+      if (hipMemsetAsync(br[i].ws + bp.queue2, 0, QUEUE_SLOTS * sizeof(unsigned), si[i]) != hipSuccess)
+        return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
+      br[i].side = h->streams[2 + i];
+      br[i].ev_bptt = h->ev_side[i][0];
+      br[i].ev_wg[0] = h->ev_side[i][1];
+      br[i].ev_wg[1] = h->ev_side[i][2];
+    }
     run[i].ws = br[i].ws;
     run[i].pl = Plan{};
     run[i].pl.queue = bp.queue;
@@ -1957,7 +2012,8 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
       return rc;
   return DPTNAV_OK;
   };
-  if (int rc = join_after(h, st, sp.nhalf == 2, enqueue())) return rc;
+  // (all four internal streams are joined: the side streams carry the LSTM weight gradients, also after an error)
+  if (int rc = join_after(h, st, sp.nhalf == 2, enqueue(), sp.nhalf == 2 && h->opt_wgrad_side ? 4 : 2)) return rc;
   if (sp.nhalf == 2) {
     const int n = (int)h->names.size();
     for (int lo = 0; lo < n; lo += GRAD_ADD_MAX) {
@@ -1999,6 +2055,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "fold_tail") h->opt_fold_tail = value != 0;
   else if (k == "wgrad_ride") h->opt_wgrad_ride = value != 0;
+  else if (k == "wgrad_side") h->opt_wgrad_side = value != 0;
   else if (k == "sub_batches" && value >= 0 && value <= MAX_SUB) h->opt_sub_batches = value;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
