@@ -146,7 +146,7 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def train_step_leg(cfg, dev, T, B=16, warmup=2, steps=5):
+def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12):
     """BASELINE configs[3] next to the headline (N=1): a few optimizer steps of the same model at batch 16 -- forward with
     tape, device PIT SI-SNR loss, HIP backward, device clip + AdamW, attention dropout 0.1 -- so that the driver-run line
     carries a training-step figure too (`--config dptn_av_train` is the full-length measurement)."""
