@@ -602,47 +602,61 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
 
   constexpr int R4 = DH / 4;
   if constexpr (PHASE == 0) {
-  // ---- stage K, V rows of this (sequence, head); rows >= len are zero --------------------------------
-  for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
-    const int p = idx / R4, f = idx % R4;
-    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-    if (p < len) {
-      const float* row = qkv + (tok0 + (int64_t)p * tstride) * ld3 + head * DH + 4 * f;
-      k4 = *reinterpret_cast<const float4*>(row + N);
-      v4 = *reinterpret_cast<const float4*>(row + 2 * N);
+  // ---- every global load of the workgroup is requested up front: this lane's q / dO / O row fragments and the K, V
+  //      rows to stage (rows >= len are zero).  (First version: a staging loop that waited for each pair of loads
+  //      before its LDS store, then the barrier, then the row fragments -- five exposed round trips per workgroup.)
+  const int qb = wv;
+  const int p = qb * 32 + c;
+  float4 q4r[DH / 8], d4r[DH / 8], o4r[DH / 8];
+  {
+    const int64_t tok = tok0 + (int64_t)(p < len ? p : 0) * tstride;
+    const float* qrow = qkv + tok * ld3 + head * DH + 4 * hh;
+    const float* drow = datt + tok * N + head * DH + 4 * hh;
+    const float* orow = att + tok * N + head * DH + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < DH / 8; ++m) {
+      q4r[m] = *reinterpret_cast<const float4*>(qrow + 8 * m);
+      d4r[m] = *reinterpret_cast<const float4*>(drow + 8 * m);
+      o4r[m] = *reinterpret_cast<const float4*>(orow + 8 * m);
     }
-    *reinterpret_cast<float4*>(&Ks[p * LD + 4 * f]) = k4;
-    *reinterpret_cast<float4*>(&Vs[p * LD + 4 * f]) = v4;
+  }
+  constexpr int NST = (ROWS * R4) / (64 * NKB);
+  static_assert((ROWS * R4) % (64 * NKB) == 0, "staging map");
+  float4 kst[NST], vst[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = i * (64 * NKB) + tid;
+    const int pr = idx / R4, f = idx % R4;
+    const float* row = qkv + (tok0 + (int64_t)(pr < len ? pr : len - 1) * tstride) * ld3 + head * DH + 4 * f;
+    kst[i] = mask4(*reinterpret_cast<const float4*>(row + N), pr < len);
+    vst[i] = mask4(*reinterpret_cast<const float4*>(row + 2 * N), pr < len);
+  }
+  // softmax statistics of this lane's query, from the training forward's tape (attention.h): one key block at a time
+  // is enough then -- S^T tile, dP^T tile, dS, dQ -- instead of the whole score row (80 registers less)
+  float2 ms = fstats[(tok0 + (int64_t)(p < len ? p : 0) * tstride) * heads + head];
+  if (p >= len) ms = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int idx = i * (64 * NKB) + tid;
+    const int pr = idx / R4, f = idx % R4;
+    *reinterpret_cast<float4*>(&Ks[pr * LD + 4 * f]) = kst[i];
+    *reinterpret_cast<float4*>(&Vs[pr * LD + 4 * f]) = vst[i];
   }
   __syncthreads();
 
   // =================================== phase A: wave = query block ===================================
   {
-    const int qb = wv;
-    const int p = qb * 32 + c;
     float qf[DH / 2], df[DH / 2];
     float dsum = 0.f;
-    {
-      const int64_t tok = tok0 + (int64_t)(p < len ? p : 0) * tstride;
-      const float* qrow = qkv + tok * ld3 + head * DH + 4 * hh;
-      const float* drow = datt + tok * N + head * DH + 4 * hh;
-      const float* orow = att + tok * N + head * DH + 4 * hh;
 #pragma unroll
-      for (int m = 0; m < DH / 8; ++m) {
-        float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * m);
-        float4 d4 = *reinterpret_cast<const float4*>(drow + 8 * m);
-        float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * m);
-        if (p >= len) q4 = d4 = o4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        qf[4 * m + 0] = q4.x * sl2e; qf[4 * m + 1] = q4.y * sl2e; qf[4 * m + 2] = q4.z * sl2e; qf[4 * m + 3] = q4.w * sl2e;
-        df[4 * m + 0] = d4.x; df[4 * m + 1] = d4.y; df[4 * m + 2] = d4.z; df[4 * m + 3] = d4.w;
-        dsum += d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
-      }
+    for (int m = 0; m < DH / 8; ++m) {
+      float4 q4 = q4r[m], d4 = d4r[m], o4 = o4r[m];
+      if (p >= len) q4 = d4 = o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[4 * m + 0] = q4.x * sl2e; qf[4 * m + 1] = q4.y * sl2e; qf[4 * m + 2] = q4.z * sl2e; qf[4 * m + 3] = q4.w * sl2e;
+      df[4 * m + 0] = d4.x; df[4 * m + 1] = d4.y; df[4 * m + 2] = d4.z; df[4 * m + 3] = d4.w;
+      dsum += d4.x * o4.x + d4.y * o4.y + d4.z * o4.z + d4.w * o4.w;
     }
     const float delta = dsum + __shfl_xor(dsum, 32);
-    // softmax statistics of this lane's query, from the training forward's tape (attention.h): one key block at a time
-    // is enough then -- S^T tile, dP^T tile, dS, dQ -- instead of the whole score row (80 registers less)
-    float2 ms = make_float2(0.f, 0.f);
-    if (p < len) ms = fstats[(tok0 + (int64_t)p * tstride) * heads + head];
     const float mx = ms.x, inv = ms.y;
     // per-query dropout seed: used here and handed to phase B with the statistics
     const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head);
@@ -711,22 +725,30 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         vf[4 * m + 0] = v4.x; vf[4 * m + 1] = v4.y; vf[4 * m + 2] = v4.z; vf[4 * m + 3] = v4.w;
       }
     }
-    // stage Q and dO rows and the per-query statistics of phase A
-    for (int p = tid; p < ROWS; p += 64 * NKB) {
-      float4 st4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < len) st4 = *reinterpret_cast<const float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4);
-      St[p] = st4;
-    }
-    for (int idx = tid; idx < ROWS * R4; idx += 64 * NKB) {
+    // stage Q and dO rows and the per-query statistics of phase A: all loads requested before the first LDS store
+    constexpr int NST = (ROWS * R4) / (64 * NKB);
+    static_assert((ROWS * R4) % (64 * NKB) == 0 && ROWS <= 64 * NKB, "staging map");
+    float4 qst[NST], dst_[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = i * (64 * NKB) + tid;
       const int p = idx / R4, f = idx % R4;
-      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = q4;
-      if (p < len) {
-        const int64_t tok = tok0 + (int64_t)p * tstride;
-        q4 = *reinterpret_cast<const float4*>(qkv + tok * ld3 + head * DH + 4 * f);
-        d4 = *reinterpret_cast<const float4*>(datt + tok * N + head * DH + 4 * f);
-      }
-      *reinterpret_cast<float4*>(&Qs[p * LD + 4 * f]) = q4;
-      *reinterpret_cast<float4*>(&Ds[p * LD + 4 * f]) = d4;
+      const int64_t tok = tok0 + (int64_t)(p < len ? p : len - 1) * tstride;
+      qst[i] = mask4(*reinterpret_cast<const float4*>(qkv + tok * ld3 + head * DH + 4 * f), p < len);
+      dst_[i] = mask4(*reinterpret_cast<const float4*>(datt + tok * N + head * DH + 4 * f), p < len);
+    }
+    {
+      const int p = tid < ROWS ? tid : ROWS - 1;
+      const float4 st4 = mask4(*reinterpret_cast<const float4*>(stats + ((tok0 + (int64_t)(p < len ? p : len - 1) * tstride) * heads + head) * 4),
+                               p < len);
+      if (tid < ROWS) St[p] = st4;
+    }
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int idx = i * (64 * NKB) + tid;
+      const int p = idx / R4, f = idx % R4;
+      *reinterpret_cast<float4*>(&Qs[p * LD + 4 * f]) = qst[i];
+      *reinterpret_cast<float4*>(&Ds[p * LD + 4 * f]) = dst_[i];
     }
     __syncthreads();
     f32x16 dk = zero16(), dv = zero16();
