@@ -229,7 +229,7 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "wgrad_ride" (0/1, default 1): training forms the out-projection and ffn.1 weight / bias gradients inside the
  *                 data-gradient GEMMs of those layers (they stage the same dY tile); 0 = separate weight-gradient launches.
  *   "wgrad_side" (0/1, default 1): training with a split batch runs the LSTM weight-gradient launches on a side stream per
- *                 half (second dP buffer in the backward workspace); 0 = in the half's own stream.
+ *                 half (two more dP buffers in the backward workspace); 0 = in the half's own stream.
  *   "sub_batches" (0..32, default 0): how many sub-batches dptnav_forward cuts a batch into; 0 = its own rule (as few
  *                 as make every recurrence launch fit the chip in one round, at least two).  A measurement knob
  *                 (tools/subbatch_sweep.py): results of different cuts agree to fp32 rounding, not bit for bit.  Set it

@@ -101,7 +101,7 @@ struct dptnav_ctx {
   static constexpr int NSTREAMS = 4;   // internal streams (dptnav_forward uses min(sub-batches, NSTREAMS); training two)
   hipStream_t streams[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NSTREAMS] = {nullptr, nullptr, nullptr, nullptr}, ev_lstm[2] = {nullptr, nullptr};
-  hipEvent_t ev_side[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // side streams of the training backward
+  hipEvent_t ev_side[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // side streams of the training backward
   bool opt_wgrad_side = true;       // training, split batches: LSTM weight gradients on a side stream per half
   int opt_sub_batches = 0;          // 0: forward_split decides; n > 0: that many sub-batches (experiments)
   std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
@@ -116,7 +116,7 @@ struct dptnav_ctx {
   int ensure_streams() {
     if (streams[0]) return 0;
     for (int i = 0; i < 2; ++i)
-      for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 4; ++k)
         if (hipEventCreateWithFlags(&ev_side[i][k], hipEventDisableTiming) != hipSuccess) {
           err = "cannot create internal streams/events";
           return 4;
@@ -729,7 +729,7 @@ struct PathTape {  // offsets in floats inside one path's tape
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
-  size_t dg2, slab2, queue2;   // second dP buffer / slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
+  size_t dg2, dg3, slab2, queue2;   // second dP buffer / slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
   int slab_wgs;
 };
 constexpr int BWD_LNP_WGS = 2048;       // upper bound of GEMM-engine workgroups writing LayerNorm partials
@@ -768,6 +768,7 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv
   p->dqkv = take((size_t)M * 3 * N);
   p->slab = take((size_t)BWD_SLAB_WGS * 512 * 128);
   p->dg2 = take((size_t)MD * 2 * 4 * H);
+  p->dg3 = take((size_t)MD * 2 * 4 * H);
   p->slab2 = take((size_t)BWD_SLAB_WGS * 512 * 128);
   p->queue2 = take(QUEUE_SLOTS);
   p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
@@ -797,8 +798,8 @@ struct BwdRun {
   // half's BPTT (8.9 ms per step with 114 CUs idle in the kernel timeline).  dP alternates between two buffers: the BPTT
   // of path p-2 waits for the weight gradients of path p to have read theirs.
   hipStream_t side = nullptr;
-  hipEvent_t ev_bptt = nullptr, ev_wg[2] = {nullptr, nullptr};
-  bool wg_pending[2] = {false, false};
+  hipEvent_t ev_bptt = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
+  bool wg_pending[3] = {false, false, false};
   int dg_sel = 0, side_slot = 0;
   unsigned* take_queue_side(int n) {   // own counters: the main stream re-zeroes its region while side launches may be in flight
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue2) + side_slot;
@@ -987,7 +988,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
   const bool side = br.side != nullptr && c->opt_wgrad2;
   if (side) {   // this path's dP goes to the buffer the weight gradients of two paths ago have (or will have) read
-    if (br.dg_sel) DG = br.ws + br.pl.dg2;
+    if (br.dg_sel) DG = br.ws + (br.dg_sel == 1 ? br.pl.dg2 : br.pl.dg3);
     if (br.wg_pending[br.dg_sel] && hipStreamWaitEvent(st, br.ev_wg[br.dg_sel], 0) != hipSuccess)
       return c->fail(DPTNAV_ERR_HIP, "side stream wait");
   }
@@ -1038,7 +1039,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         return rc;
       if (hipEventRecord(br.ev_wg[br.dg_sel], br.side) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream record");
       br.wg_pending[br.dg_sel] = true;
-      br.dg_sel ^= 1;
+      br.dg_sel = (br.dg_sel + 1) % 3;
     } else {
       if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, br.take_queue(4)))
         return rc;
@@ -1381,7 +1382,7 @@ void dptnav_destroy(dptnav_handle h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (hipEvent_t e : h->ev_sub) hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
       if (h->ev_side[i][k]) hipEventDestroy(h->ev_side[i][k]);
   delete h;
 }
@@ -1970,6 +1971,7 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
       br[i].ev_bptt = h->ev_side[i][0];
       br[i].ev_wg[0] = h->ev_side[i][1];
       br[i].ev_wg[1] = h->ev_side[i][2];
+      br[i].ev_wg[2] = h->ev_side[i][3];
     }
     run[i].ws = br[i].ws;
     run[i].pl = Plan{};
