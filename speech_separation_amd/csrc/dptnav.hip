@@ -729,7 +729,7 @@ struct PathTape {  // offsets in floats inside one path's tape
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
-  size_t dg2, dg3, slab2, queue2;   // second dP buffer / slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
+  size_t dg2, dg3, slab2, queue2;   // more dP buffers / second slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
   int slab_wgs;
 };
 constexpr int BWD_LNP_WGS = 2048;       // upper bound of GEMM-engine workgroups writing LayerNorm partials
@@ -795,8 +795,8 @@ struct BwdRun {
   hipEvent_t lstm_record = nullptr;
   // Side stream (option wgrad_side, split batches): nothing needs dW before the step ends, so the LSTM weight-gradient
   // launches leave the half's chain and run whenever CUs are free -- in particular while this half waits for the other
-  // half's BPTT (8.9 ms per step with 114 CUs idle in the kernel timeline).  dP alternates between two buffers: the BPTT
-  // of path p-2 waits for the weight gradients of path p to have read theirs.
+  // half's BPTT (8.9 ms per step with 114 CUs idle in the kernel timeline).  dP rotates through three buffers: the BPTT
+  // of path p-3 waits for the weight gradients of path p to have read theirs.
   hipStream_t side = nullptr;
   hipEvent_t ev_bptt = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
   bool wg_pending[3] = {false, false, false};
