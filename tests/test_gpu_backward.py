@@ -265,6 +265,42 @@ def test_split_training_step_equals_unsplit(dev):
     assert worst[0] > 90, worst
 
 
+def test_weight_gradient_schedules_agree(dev):
+    """Where the weight gradients are formed is a schedule, not arithmetic: riding on the data-gradient GEMMs (option
+    wgrad_ride), on a side stream per half with rotating dP buffers (wgrad_side), both in one pass over dP (wgrad2) -- or
+    as stand-alone launches in the half's own stream.  Four paths deep so that every dP buffer is reused; every
+    gradient must agree with the plain schedule's to fp32 summation order, and with dropout on (same seed) too."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import synthetic_inputs
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2})
+    sd = synthetic_state_dict(cfg, seed=6)
+    B, T, Tv = 4, 2600, 13
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=12)
+    rng = np.random.default_rng(13)
+    d1 = torch.from_numpy(rng.standard_normal((B, T)).astype(np.float32)).to(dev)
+    d2 = torch.from_numpy(rng.standard_normal((B, T)).astype(np.float32)).to(dev)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    results = {}
+    for name, opts in {"default": {}, "plain": {"wgrad_ride": 0, "wgrad_side": 0, "wgrad2": 0},
+                       "no side stream": {"wgrad_side": 0}, "no riders": {"wgrad_ride": 0}}.items():
+        eng = DptnEngine(cfg, dev)
+        eng.bind(params_to_device(sd, dev))
+        grads = eng.bind_grads()
+        eng.set_option("dropout_ppm", 100000)
+        eng.set_option("dropout_seed", 99)
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        for _ in range(2):      # twice: the second backward reuses events, buffers and ticket counters of the first
+            s1, s2, tape = eng.train_forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
+            eng.train_backward(t["mix"], t["s1_embedding"], t["s2_embedding"], d1, d2, tape)
+        torch.cuda.synchronize()
+        results[name] = {k: g.cpu().numpy().copy() for k, g in grads.items()}
+        del eng
+    for name in ("default", "no side stream", "no riders"):
+        worst = min((O.agreement_db(results[name][k], results["plain"][k]), k) for k in results["plain"])
+        assert worst[0] > 90, (name, worst)
+
+
 def test_full_size_training_step_is_deterministic(dev):
     """B=16, T=32000 (BASELINE config 4, dropout 0.1): two forward/backward passes with the same dropout seed give
     bit-identical outputs; the parameter gradients agree to fp32 summation order (the token reductions hand their tiles
