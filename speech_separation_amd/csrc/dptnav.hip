@@ -660,7 +660,7 @@ int run_head(dptnav_ctx* c, Run& run, const float* mix, const float* e1, const f
   }
   constexpr int FPB = 256 / (N / 4);
   ProfScope ps(c, CAT_ENCODER, st);
-  hipLaunchKernelGGL(encoder_fuse_kernel<N>, dim3((unsigned)((pl.L + FPB - 1) / FPB), B), dim3(256), 0, st, mix,
+  hipLaunchKernelGGL(encoder_fuse_kernel<N>, dim3((unsigned)((pl.L + FPB * ENC_PASSES - 1) / (FPB * ENC_PASSES)), B), dim3(256), 0, st, mix,
                      c->w("encoder.weight"), vid, g.audio_only ? nullptr : c->w("gate"),
                      g.audio_only ? nullptr : c->w("video_ln.weight"), g.audio_only ? nullptr : c->w("video_ln.bias"),
                      E, X, T, (int)pl.L, g.kernel_size_enc, c->stride, Tv, (int)pl.S, g.chunk_size, g.step_size);

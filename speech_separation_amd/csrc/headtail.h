@@ -39,6 +39,8 @@ __global__ __launch_bounds__(256) void video_linear_kernel(const float* __restri
 //       + write the frame-major latent E[b][l][n] and the chunked tokens X[b][s][k][n]
 //   reference: dptn_wav.py:180-184, dprnn.py:122-136.   GROUP = N/4 lanes per frame.
 // ------------------------------------------------------------------------------------------------
+constexpr int ENC_PASSES = 8;   // passes of 256 / (N/4) frames per workgroup
+constexpr int ENC_KMAX = 8;     // encoder taps held in registers (kernel_size_enc is in [2, 8]: dptnav_create)
 template <int N>
 __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restrict__ mix,
                                                             const float* __restrict__ wenc,  // (N,1,k)
@@ -50,19 +52,37 @@ __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restri
                                                             int64_t T, int L, int kenc, int stride, int Tv, int S,
                                                             int K, int P) {
   constexpr int GROUP = N / 4;
-  constexpr int FPB = 256 / GROUP;  // frames per block
+  constexpr int FPB = 256 / GROUP;  // frames per pass
   const int b = blockIdx.y;
-  const int l = blockIdx.x * FPB + threadIdx.x / GROUP;
   const int c4 = threadIdx.x % GROUP;
+  // ENC_PASSES passes of FPB frames per workgroup, the encoder taps of this thread's 4 channels held in registers (one
+  // pass per workgroup meant 10.7 k workgroups of a few hundred cycles each for a half batch: the launch ran at the
+  // dispatch rate, 0.9 TB/s)
+  float we[4][ENC_KMAX];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < ENC_KMAX; ++j) we[i][j] = j < kenc ? wenc[(4 * c4 + i) * kenc + j] : 0.f;
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga;
+  float tg = 0.f;
+  if (vid != nullptr) {
+    ga = *reinterpret_cast<const float4*>(ln_w + 4 * c4);
+    be = *reinterpret_cast<const float4*>(ln_b + 4 * c4);
+    tg = tanhf(*gate);
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < ENC_PASSES; ++pass) {
+  const int l = (blockIdx.x * ENC_PASSES + pass) * FPB + threadIdx.x / GROUP;
   const bool ok = l < L;
   const int lc = ok ? l : L - 1;
 
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   const float* m = mix + (int64_t)b * T + (int64_t)stride * lc;
-  for (int j = 0; j < kenc; ++j) {
-    const float x = m[j];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = fmaf(wenc[(4 * c4 + i) * kenc + j], x, v[i]);
+  for (int j = 0; j < ENC_KMAX; ++j) {
+    const float x = j < kenc ? m[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = fmaf(we[i][j], x, v[i]);
   }
   if (vid != nullptr) {
     // F.interpolate(mode="linear", align_corners=False)
@@ -86,22 +106,21 @@ __global__ __launch_bounds__(256) void encoder_fuse_kernel(const float* __restri
     }
     q = group_sum<GROUP>(q);
     const float rstd = rsqrtf(q * (1.0f / N) + 1e-5f);
-    const float tg = tanhf(*gate);
-    const float4 ga = *reinterpret_cast<const float4*>(ln_w + 4 * c4);
-    const float4 be = *reinterpret_cast<const float4*>(ln_b + 4 * c4);
     v[0] += tg * (u[0] * rstd * ga.x + be.x);
     v[1] += tg * (u[1] * rstd * ga.y + be.y);
     v[2] += tg * (u[2] * rstd * ga.z + be.z);
     v[3] += tg * (u[3] * rstd * ga.w + be.w);
   }
-  if (!ok) return;
-  const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4*>(E + ((int64_t)b * L + l) * N + 4 * c4) = o4;
-  // chunks s with P*s <= l < P*s + K   (F.unfold semantics: trailing frames belong to no chunk)
-  int s_hi = l / P;
-  if (s_hi > S - 1) s_hi = S - 1;
-  for (int s = s_hi; s >= 0 && l - P * s < K; --s)
-    *reinterpret_cast<float4*>(X + (((int64_t)b * S + s) * K + (l - P * s)) * N + 4 * c4) = o4;
+  if (ok) {
+    const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(E + ((int64_t)b * L + l) * N + 4 * c4) = o4;
+    // chunks s with P*s <= l < P*s + K   (F.unfold semantics: trailing frames belong to no chunk)
+    int s_hi = l / P;
+    if (s_hi > S - 1) s_hi = S - 1;
+    for (int s = s_hi; s >= 0 && l - P * s < K; --s)
+      *reinterpret_cast<float4*>(X + (((int64_t)b * S + s) * K + (l - P * s)) * N + 4 * c4) = o4;
+  }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
