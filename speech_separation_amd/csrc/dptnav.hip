@@ -1266,8 +1266,17 @@ int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* 
     hipLaunchKernelGGL(gate_grad_finish_kernel, dim3(1), dim3(128), 0, st, red, c->w("gate"), c->w("video_ln.bias"), G("gate"),
                        G("video_ln.weight"), G("video_ln.bias"), N);
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(Tv, B), dim3(128), 0, st, DVI, DV, N, (int)L, Tv);
-    hipLaunchKernelGGL(video_linear_bwd_kernel, dim3(g.hidden_video / 2), dim3(256), 0, st, DV, e1, e2,
-                       G("visual_compression.weight"), G("visual_compression.bias"), B, g.video_emb_size, Tv, g.hidden_video / 2);
+    {
+      if (Tv > 256) return c->fail(DPTNAV_ERR_INVALID, "training step: more than 256 video frames (Tv=%d)", Tv);
+      const int half = g.hidden_video / 2;
+      const int64_t wcnt = (int64_t)half * g.video_emb_size;
+      float* colslab = slab + (size_t)B * wcnt;
+      hipLaunchKernelGGL(video_linear_bwd_kernel, dim3(half, B), dim3(256), 0, st, DV, e1, e2, slab, colslab, g.video_emb_size, Tv, half);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wcnt + 31) / 32)), dim3(256), 0, st, slab, B, wcnt,
+                         G("visual_compression.weight"), 0);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((half + 31) / 32), dim3(256), 0, st, colslab, B, (int64_t)half,
+                         G("visual_compression.bias"), 0);
+    }
     LAUNCH_CHECK(c, "video branch backward");
   }
   {
