@@ -308,19 +308,25 @@ __global__ __launch_bounds__(256) void encoder_wgrad_kernel(const float* __restr
 }
 
 // linear-interpolation backward (transpose of F.interpolate align_corners=False): DV[b][tv][c] = sum_l w(l,tv) DVI[b][l][c]
-__global__ __launch_bounds__(128) void interp_bwd_kernel(const float* __restrict__ DVI, float* __restrict__ DV, int N, int L,
+// 512 threads = 4 window quarters x 128 channels (N <= 128); a thread walks its quarter of the
+// frames that can touch tv with UNCONDITIONAL loads (weight 0 where they do not: eight in flight), the quarters are
+// summed in a fixed order.  (One thread per channel walking the whole window behind a branch: 0.19 ms per launch.)
+__global__ __launch_bounds__(512) void interp_bwd_kernel(const float* __restrict__ DVI, float* __restrict__ DV, int N, int L,
                                                           int Tv) {
+  __shared__ float part[4][128];
   const int b = blockIdx.y, tv = blockIdx.x;
+  const int c = threadIdx.x & 127, qd = threadIdx.x >> 7;
   const float scale = (float)Tv / (float)L;
-  // frames whose i0 or i1 can equal tv: src in (tv-1, tv+1)  ->  l in a window; scan it (deterministic order)
+  // frames whose i0 or i1 can equal tv: src in (tv-1, tv+1)  ->  l in a window
   int lo = (int)floorf(((float)tv - 1.0f + 0.5f) / scale - 0.5f) - 2;
   int hi = (int)ceilf(((float)tv + 1.0f + 0.5f) / scale - 0.5f) + 2;
   lo = lo < 0 ? 0 : lo;
   hi = hi > L - 1 ? L - 1 : hi;
   if (tv == 0) lo = 0;
-  for (int c = threadIdx.x; c < N; c += blockDim.x) {
-    float s = 0.f;
-    for (int l = lo; l <= hi; ++l) {
+  float s = 0.f;
+  if (c < N) {
+#pragma unroll 8
+    for (int l = lo + qd; l <= hi; l += 4) {
       float src = ((float)l + 0.5f) * scale - 0.5f;
       src = src < 0.f ? 0.f : src;
       const int i0 = (int)floorf(src);
@@ -329,10 +335,12 @@ __global__ __launch_bounds__(128) void interp_bwd_kernel(const float* __restrict
       float wgt = 0.f;
       if (i0 == tv) wgt += 1.f - lam;
       if (i1 == tv) wgt += lam;
-      if (wgt != 0.f) s = fmaf(wgt, DVI[((int64_t)b * L + l) * N + c], s);
+      s = fmaf(wgt, DVI[((int64_t)b * L + l) * N + c], s);
     }
-    DV[((int64_t)b * Tv + tv) * N + c] = s;
   }
+  part[qd][c] = s;
+  __syncthreads();
+  if (qd == 0 && c < N) DV[((int64_t)b * Tv + tv) * N + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // visual_compression gradients: dW[o][cv] = sum_{b,t,spk} DV[b][t][spk*half + o] e_spk[b][cv][t]; db[o] = sum DV.

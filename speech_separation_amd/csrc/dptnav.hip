@@ -690,8 +690,9 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
   // T2: overlap-add gather -> post-processing conv -> + E -> decoder tap products
   const int ola = (int)((pl.S - 1) * g.step_size + g.chunk_size);
   const int left = (int)((pl.L - ola) / 2);
-  if (Zbuf == nullptr && c->opt_fold_tail) {
-    // inference: the three linear steps folded into one contraction of length 2N per frame (headtail.h)
+  if (c->opt_fold_tail) {
+    // the three linear steps folded into one contraction of length 2N per frame (headtail.h); the training forward too:
+    // its backward recomputes q from Z and E itself (run_tail_backward), nothing of the GEMM form is kept
     float* Wf = ws + pl.wfold;
     ProfScope ps(c, CAT_POST, st);
     hipLaunchKernelGGL(fold_decoder_kernel<N>, dim3(8), dim3(N), 0, st, c->w("dprnn.postprocessing.0.weight"),
@@ -1265,7 +1266,7 @@ int run_head_backward(dptnav_ctx* c, BwdRun& br, const float* mix, const float* 
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, st, slab, (int)(gx * B), cnt, red, 0);
     hipLaunchKernelGGL(gate_grad_finish_kernel, dim3(1), dim3(128), 0, st, red, c->w("gate"), c->w("video_ln.bias"), G("gate"),
                        G("video_ln.weight"), G("video_ln.bias"), N);
-    hipLaunchKernelGGL(interp_bwd_kernel, dim3(Tv, B), dim3(128), 0, st, DVI, DV, N, (int)L, Tv);
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(Tv, B), dim3(512), 0, st, DVI, DV, N, (int)L, Tv);
     {
       if (Tv > 256) return c->fail(DPTNAV_ERR_INVALID, "training step: more than 256 video frames (Tv=%d)", Tv);
       const int half = g.hidden_video / 2;
