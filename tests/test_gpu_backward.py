@@ -339,3 +339,50 @@ def test_full_size_training_step_is_deterministic(dev):
             assert float(10 * torch.log10(a.pow(2).sum() / (a - b).pow(2).sum().clamp_min(1e-300))) > 90, k
     assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][2]).all()
     assert float(runs[0][2].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
+@pytest.mark.parametrize("name,copies", [("grad_mid_av", 1), ("grad_full_av", 1), ("grad_full_av", 16)])
+def test_training_step_matches_reference_gradients(dev, golden, name, copies, lstm_tile):
+    """BASELINE config 4 against the REFERENCE's own numbers: tests/golden/grad_*.npz hold the loss and d loss / d every
+    parameter that the imported reference produced with `model.train(); outputs = model(**batch); SiSNRWavLoss;
+    loss.backward()` (trainer.py:40-47, ss_losses.py:21-26,96-130, dptn_wav.py:171-194; dropout 0.0 -- tools/gen_golden.py).
+    Here the same step runs through the drop-in nn.Module (dptnav_train_forward / dptnav_train_backward) and the device
+    loss (dptnav_pit_sisnr_loss).  `copies` = 16 repeats the fixture's one mixture over the batch of config 4
+    (B=16 x T=32000, 6 blocks): the batch mean of 16 identical terms is the single term, so loss and gradients must
+    reproduce the B=1 reference numbers while every kernel runs at its full BASELINE size (two halves, two streams)."""
+    from speech_separation_amd import DPTNAVWavEncDec
+    from speech_separation_amd.spec import synthetic_inputs
+    from speech_separation_amd.train import SiSNRWavLoss
+    from tests.test_oracle_golden import reference_gradient_report
+    from tools.gen_golden import weights_digest
+    cfg, z = golden(name)
+    B, T, Tv = (int(v) for v in z["shape"])
+    wseed, iseed = (int(v) for v in z["seeds"])
+    sd = synthetic_state_dict(cfg, seed=wseed)
+    assert weights_digest(sd) == str(z["digest"])
+    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
+    model = DPTNAVWavEncDec(**kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).train()
+    model._get_engine(dev).set_option("lstm16", 1 if lstm_tile == 16 else 0)
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=iseed)
+    batch = {k: torch.from_numpy(np.repeat(v, copies, axis=0)).to(dev) for k, v in inp.items()}
+    batch.update(model(mix_spectrogram=torch.zeros(1, device=dev), **batch))
+    loss = SiSNRWavLoss()(**batch)["loss"]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["val.loss"])) < 1e-4 * abs(float(z["val.loss"])), (float(loss), float(z["val.loss"]))
+    for k in ("s1_pred", "s2_pred"):        # the training forward reproduces the reference's train-mode outputs, every row
+        for r in range(0, B * copies, B):
+            assert O.agreement_db(batch[k][r:r + B].detach().cpu().numpy(), z["tap." + k]) > 80, (k, r)
+    grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+    worst_db, worst_norm = reference_gradient_report(z, grads)
+    assert worst_db[0] > 60, worst_db
+    assert worst_norm[0] < 1e-3, worst_norm
+    total = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    assert abs(total - float(z["val.grad_norm"])) < 1e-4 * float(z["val.grad_norm"])
+    # the fused clip sees the same global norm the reference's clip_grad_norm_ would (base_trainer.py:383-391)
+    from speech_separation_amd.train import clip_grad_norm_
+    norm = clip_grad_norm_(model, 10.0)
+    assert abs(float(norm) - float(z["val.grad_norm"])) < 1e-4 * float(z["val.grad_norm"])

@@ -137,3 +137,63 @@ def test_convtasnet_stock_composition_matches_reference():
     out = CT.forward({k: torch.from_numpy(v) for k, v in sd.items()}, torch.from_numpy(mix))
     for k in ("s1_pred", "s2_pred"):
         assert out[k].shape == (2, 4000) and O.agreement_db(out[k].numpy(), z[k]) > 100
+
+
+def reference_gradient_report(z, grads):
+    """Compare {state_dict key: gradient array} with a tests/golden/grad_*.npz record of the REFERENCE's loss.backward()
+    (tools/gen_golden.py::reference_gradients): -> (worst agreement in dB over parameters, its key, worst relative norm
+    error, its key).  Small tensors are stored whole, big ones as every `stride`-th element."""
+    stride, full_below = int(z["stride"]), int(z["full_below"])
+    worst_db, worst_norm = (1e9, None), (0.0, None)
+    keys = [k[5:] for k in z if k.startswith("grad.")]
+    assert sorted(keys) == sorted(grads), set(keys) ^ set(grads)
+    for k in keys:
+        g = np.asarray(grads[k], dtype=np.float64)
+        want = z["grad." + k]
+        got = g.reshape(want.shape) if g.size <= full_below else g.reshape(-1)[::stride]
+        db = O.agreement_db(got, want)
+        nrm = float(np.sqrt((g ** 2).sum()))
+        rel = abs(nrm - float(z["norm." + k])) / max(float(z["norm." + k]), 1e-30)
+        if db < worst_db[0]:
+            worst_db = (db, k)
+        if rel > worst_norm[0]:
+            worst_norm = (rel, k)
+    return worst_db, worst_norm
+
+
+@pytest.mark.parametrize("name", ["grad_tiny_av", "grad_mid_av"])
+def test_stock_autograd_matches_reference_gradients(golden, name):
+    """The gradient oracle of the GPU backward tests (torch.autograd through oracle/torch_stock.py + SiSNRWavLossTorch)
+    reproduces what the REFERENCE's own training step produced: loss (ss_losses.py:21-26,96-130) and d loss / d every
+    parameter after loss.backward() (trainer.py:40-47), captured by tools/gen_golden.py from the imported reference."""
+    import torch
+    from oracle.torch_stock import SiSNRWavLossTorch, StockDPTN
+    cfg, z = golden(name)
+    B, T, Tv = (int(v) for v in z["shape"])
+    wseed, iseed = (int(v) for v in z["seeds"])
+    sd = synthetic_state_dict(cfg, seed=wseed)
+    assert weights_digest(sd) == str(z["digest"])
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=iseed)
+    ref = StockDPTN(cfg, sd)
+    ref.sd = {k: v.requires_grad_(True) for k, v in ref.sd.items()}
+    for _, m, r in ref.paths:
+        for p in list(m.parameters()) + list(r.parameters()):
+            p.requires_grad_(True)
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with torch.enable_grad():
+        batch.update(StockDPTN.__call__.__wrapped__(ref, **batch))
+        loss = SiSNRWavLossTorch()(**batch)["loss"]
+        loss.backward()
+    assert abs(float(loss) - float(z["val.loss"])) < 1e-4 * abs(float(z["val.loss"]))
+    grads = {}
+    for pre, m, r in ref.paths:
+        grads[pre + "mha.in_proj_weight"], grads[pre + "mha.in_proj_bias"] = m.in_proj_weight.grad, m.in_proj_bias.grad
+        grads[pre + "mha.out_proj.weight"], grads[pre + "mha.out_proj.bias"] = m.out_proj.weight.grad, m.out_proj.bias.grad
+        for k, v in r.named_parameters():
+            grads[pre + "rnn." + k] = v.grad
+    for k, v in ref.sd.items():
+        if k not in grads:
+            grads[k] = v.grad
+    worst_db, worst_norm = reference_gradient_report(z, {k: v.numpy() for k, v in grads.items()})
+    assert worst_db[0] > 80, worst_db
+    assert worst_norm[0] < 1e-3, worst_norm

@@ -122,6 +122,54 @@ def subsample(a: np.ndarray, step: int) -> np.ndarray:
     return np.ascontiguousarray(a.reshape(-1)[::step])
 
 
+GRAD_STRIDE = 37      # big gradients are stored as every 37th element (coprime with every tensor width on the path)
+GRAD_FULL_BELOW = 4096
+
+
+def reference_gradients(dptn_wav, losses, cfg: DPTNConfig, sd, inp):
+    """The reference's OWN training step up to loss.backward() (trainer.py:38-47): model.train(), outputs = model(**batch),
+    SiSNRWavLoss (ss_losses.py:21-26,96-130), loss.backward().  dropout must be 0.0 for a deterministic fixture (train-mode
+    attention dropout is a torch RNG stream); nn.LSTM(dropout=1) is a no-op for one layer (dptn.py:23-29)."""
+    assert cfg.dropout == 0.0
+    model = build_reference(dptn_wav, cfg, sd).train()
+    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    model.zero_grad()
+    with torch.enable_grad():
+        batch.update(model(mix_spectrogram=torch.zeros(1), **batch))
+        loss = losses.SiSNRWavLoss()(**batch)["loss"]
+        loss.backward()
+    out = {"val.loss": np.float64(loss.item()), "tap.s1_pred": batch["s1_pred"].detach().numpy(),
+           "tap.s2_pred": batch["s2_pred"].detach().numpy()}
+    total = 0.0
+    for k, p in model.named_parameters():
+        g = p.grad.detach().numpy()
+        out[f"norm.{k}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        total += float(out[f"norm.{k}"]) ** 2
+        out[f"grad.{k}"] = g.copy() if g.size <= GRAD_FULL_BELOW else subsample(g, GRAD_STRIDE)
+    out["val.grad_norm"] = np.float64(np.sqrt(total))      # what clip_grad_norm_ sees (base_trainer.py:383-391)
+    return out
+
+
+def gradient_fixtures(dptn_wav, losses, only):
+    """config 4's gradients pinned to the reference itself (not to autograd on this repo's port)."""
+    cases = [
+        ("grad_tiny_av", DPTNConfig(**{**DPTN_TINY.to_dict(), "dropout": 0.0}), dict(B=2, T=209, Tv=9), 7, 11),
+        ("grad_mid_av", DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0}), dict(B=2, T=8000, Tv=50), 0, 123),
+        ("grad_full_av", DPTNConfig(**{**DPTN_AV.to_dict(), "dropout": 0.0}), dict(B=1, T=32000, Tv=50), 0, 123),
+    ]
+    for name, cfg, shp, wseed, iseed in cases:
+        if only and name not in only:
+            continue
+        sd = synthetic_state_dict(cfg, seed=wseed)
+        inp = synthetic_inputs(cfg, seed=iseed, **shp)
+        rec = reference_gradients(dptn_wav, losses, cfg, sd, inp)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), cfg=np.array(repr(cfg.to_dict())),
+                            shape=np.array([shp["B"], shp["T"], shp["Tv"]]), seeds=np.array([wseed, iseed]),
+                            stride=np.array(GRAD_STRIDE), full_below=np.array(GRAD_FULL_BELOW),
+                            digest=np.array(weights_digest(sd)), **rec)
+        print(name, "loss", rec["val.loss"], "grad norm", rec["val.grad_norm"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -182,6 +230,9 @@ def main():
                             **{f"tap.{k}": v for k, v in keep.items()}, **{f"val.{k}": v for k, v in extra.items()})
         print(name, "loss", extra["pit_loss"], "rms", float(np.sqrt((taps['s1_pred'] ** 2).mean())))
 
+
+    # ---- 2b. the reference's loss.backward() (config 4): loss, every parameter's gradient norm, gradient samples ----
+    gradient_fixtures(dptn_wav, losses, only)
 
     # ---- 3. Conv-TasNet (BASELINE configs[0], CPU-only reference case): outputs for seeded weights ----
     if only and "convtasnet" not in only:
