@@ -11,11 +11,17 @@ Mixtures are independent, so ranks shard by batch with no data-path collective (
 collectives are the timing barrier and a MAX over ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line: the contract fields plus
-  "roofline"     -- dominant kernel (lstm_recurrence): algorithmic FLOPs per launch / its mean device time,
-                    measured live with HIP events recorded on the launch stream (dptnav_profile_*),
-  "cpu_baseline" -- oracle/torch_stock.py (stock PyTorch CPU operators = what the reference runs on CPU)
-                    timed on this box's host cores on a bounded sample (rank 0, N=1 only),
-  "kernels"      -- device ms per forward by kernel class (same HIP-event measurement).
+  "roofline"      -- the DOMINANT kernel class = the one with the largest device time per step in this very run
+                     (since round 2 the fused attention block, not the recurrence): algorithmic FLOPs per launch / its mean
+                     device time, measured live with HIP events recorded on the launch stream (dptnav_profile_*);
+                     `roofline.kernels` carries the same figures for every MFMA-bound class (attention block, LSTM
+                     recurrence, pre-activation GEMM, ...), so the line is self-consistent with profiles/*kernel_stats.csv,
+  "other_configs" -- short legs of BASELINE configs[1] (DPTN audio-only) and configs[4] (DPRNN-AV, B=32 x 8 s) and
+  "train_step"    -- of configs[3], appended to the N=1 headline run (each in a try/except: a failing optional leg is
+                     recorded as {"error": ...} and never costs the headline number),
+  "cpu_baseline"  -- oracle/torch_stock.py (stock PyTorch CPU operators = what the reference runs on CPU)
+                     timed on this box's host cores on a bounded sample (rank 0, N=1 only),
+  "kernels_ms_per_step" -- device ms per forward by kernel class (same HIP-event measurement).
 """
 from __future__ import annotations
 
@@ -124,7 +130,7 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 25.0):
             "configs0_convtasnet_cpu": {"value": round(conv_rate, 3), "unit": "mixtures/sec", "batch": 4,
                                         "note": "oracle/convtasnet_stock.py = src/model/convtasnet.py with stock PyTorch ops"},
             "sample": "oracle/torch_stock.py (stock PyTorch CPU ops, fp32, eval/no_grad), T=32000, 1 warm-up + "
-                      + "; ".join(parts) + "; max over B reported; B=16 not sampled (28.6 s per forward on 8 cores, and CPU throughput "
+                      + "; ".join(parts) + "; max over B reported, ONE sample per batch size (1.3-1.9 mixtures/s between runs of a day); B=16 not sampled (28.6 s per forward on 8 cores, and CPU throughput "
                       "falls with B: BASELINE.md section 2)"}
 
 
@@ -202,7 +208,9 @@ def bench_train(args, env, cfg, B, T, workload):
     torch.cuda.synchronize(dev)
     env.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = env.max_over_ranks(mine)
+    per_rank_s = env.gather_over_ranks(mine)
     if args.pmc_run:
         if env.rank == 0:
             print(json.dumps({"pmc_run": True, "config": args.config, "steps": args.steps, "ms_per_step": round(1e3 * elapsed / args.steps, 3)}),
@@ -238,9 +246,175 @@ def bench_train(args, env, cfg, B, T, workload):
                          if ttab else None,
                          "note": "algorithmic FLOPs = 3 x forward (612 GFLOP per mixture)"},
             "kernels_ms_per_step": {k: round(v[0] / psteps, 3) for k, v in prof.items()},
-            "last_step": {k: round(float(v), 5) for k, v in stats.items()} if stats else None,
-            "host_syncs_per_step": 0}), flush=True)
+            "rccl_ranks": env.backend_world() if env.backend == "nccl" else 0, "backend": env.backend,
+            "per_rank_mixtures_per_sec": [round(B * args.steps / t, 3) for t in per_rank_s],
+            "last_step": {k: round(float(v), 5) for k, v in stats.items()} if stats else None}), flush=True)
     env.close()
+
+
+def class_flops_per_step(cfg, prof, B, S, L):
+    """Algorithmic FLOPs (2 per MAC, GEMM-like terms only: DESIGN.md section 4 = SURVEY.md 8d) of one forward step, by the
+    kernel class that executes them IN THIS RUN: with the fused attention block (no qkv_gemm launches) the class
+    `attention` carries in-projection + scores/PV + out-projection and the FFN of every path whose K6 rode in the next
+    block's prologue (all but the ffn_ln_gemm launches that remain)."""
+    N, H, K, nb = cfg.num_features, cfg.hidden_dim, cfg.chunk_size, cfg.num_blocks
+    M = float(B) * S * K
+    paths = [(K, 2), (S, 2 if cfg.bidir else 1)]          # (sequence length, LSTM directions) of the intra / inter path
+    f = {"lstm_pre_gemm": sum(M * nb * nd * 2 * N * 4 * H for _, nd in paths),
+         "lstm_recurrence": sum(M * nb * nd * 2 * H * 4 * H for _, nd in paths),
+         "sep_gemm": M * 2 * N * 2 * N, "postproc_gemm": float(B) * L * (2 * 2 * N * N + 2 * 2 * N * cfg.kernel_size_enc)}
+    ffn = sum(M * nb * 2 * nd * H * N for _, nd in paths)
+    if cfg.arch != "dptn":
+        f["ffn_ln_gemm"] = ffn                             # DPRNN: fc + LayerNorm + residual (dprnn.py:40-46)
+        return f, False
+    qkv, outp = M * nb * 2 * 2 * N * 3 * N, M * nb * 2 * 2 * N * N
+    att = sum(M * nb * 4 * ln * N for ln, _ in paths)
+    n_att, n_ffn = prof["attention"][1], prof["ffn_ln_gemm"][1]
+    fused = prof["qkv_gemm"][1] == 0 and n_att > 0
+    if not fused:
+        f.update(qkv_gemm=qkv, attention=att, outproj_ln_gemm=outp, ffn_ln_gemm=ffn)
+        return f, False
+    ride = 1.0 - n_ffn / float(n_att) if n_ffn < n_att else 0.0
+    f["attention"] = qkv + att + outp + ffn * ride
+    f["ffn_ln_gemm"] = ffn * (1.0 - ride)
+    return f, ride > 0
+
+
+def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
+    """One row per MFMA-bound kernel class: launches, mean launch time (HIP events), algorithmic FLOPs per launch, the
+    fraction of the chip's fp32-MFMA peak; sorted by device time per step (row 0 = the dominant kernel)."""
+    S, K = eng.chunks(T), cfg.chunk_size
+    flops, ffn_rides = class_flops_per_step(cfg, prof, B, S, eng.frames(T))
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    ndir = 2 if cfg.bidir else 1
+    rows = []
+    for cls, fl in flops.items():
+        ms, n = prof.get(cls, (0.0, 0))
+        if n == 0 or fl <= 0:
+            continue
+        lps = n / float(psteps)
+        tf = fl * psteps / (ms * 1e-3) / 1e12
+        row = {"class": cls, "launches_per_step": lps, "launch_ms": round(ms / n, 4), "ms_per_step": round(ms / psteps, 4),
+               "flops_per_launch": fl / lps, "achieved": round(tf, 3), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        if cls == "lstm_recurrence":
+            # which recurrence kernel those launches were (run_path in dptnav.hip: 16-sequence tiles when a launch fits
+            # the chip in one round, i.e. for the DPTN half-batch launches; 32-sequence tiles otherwise).  A launch
+            # occupies ONE CU per (direction, sequence tile) -- W_hh fills the CU's register file -- so beside `frac`
+            # (against the whole chip's peak) the share of the chip the launch can use at all
+            b_launch = B * 2 * cfg.num_blocks / lps
+            fits16 = all(-(-int(b_launch * n_) // 16) * d <= n_cus for n_, d in ((S, 2), (K, ndir)))
+            tile = 16 if fits16 else 32
+            wgs = sum(-(-int(b_launch * n_) // tile) * d for n_, d in ((S, 2), (K, ndir))) / 2.0     # mean of intra / inter
+            occ = min(float(n_cus), wgs)
+            row.update(kernel="lstm16_kernel" if fits16 else "lstm_recurrence_kernel", pmc_match="lstm16_kernel" if fits16 else "lstm_recurrence_kernel",
+                       workgroups_per_launch=round(wgs, 1), cus_occupied=round(occ, 1), rounds=round(wgs / n_cus, 2),
+                       frac_of_occupied_cus=round(tf / (PEAK_F32_MFMA_TFLOPS * occ / n_cus), 4),
+                       algorithmic_bytes=int(B * S * K * 2 * cfg.num_blocks / lps) * (4 * cfg.hidden_dim * ndir + cfg.hidden_dim * ndir) * 4)
+        elif cls == "attention":
+            fused = prof["qkv_gemm"][1] == 0
+            row.update(kernel=("attn_block_kernel (in-proj + attention + out-proj + LN1" + (" + FFN/LN2 of the previous path)" if ffn_rides else ")"))
+                       if fused else "attention_kernel (scores, softmax, PV)", pmc_match="attn_block_kernel<5, true>" if ffn_rides else
+                       ("attn_block_kernel" if fused else "attention_kernel"))
+        else:
+            row.update(kernel={"lstm_pre_gemm": "gemm_ws_kernel<..., EpiLstmPre*> (x W_ih^T + b, fragment-order store)",
+                               "ffn_ln_gemm": "gemm_ws_kernel<..., EpiBiasResLN> (ReLU(h) W_f^T + b + y1, LayerNorm 2)",
+                               "qkv_gemm": "gemm_ws_kernel<..., EpiBiasStore> (in-projection)",
+                               "outproj_ln_gemm": "gemm_ws_kernel<..., EpiBiasResLN> (out-projection + residual + LayerNorm 1)",
+                               "sep_gemm": "gemm_ws_kernel<..., ALoadDensePReLU, EpiBiasStore> (PReLU + 1x1 conv N -> 2N)",
+                               "postproc_gemm": "taps_fold_kernel (OLA gather + post-processing conv + skip + decoder taps)"}[cls],
+                       pmc_match={"lstm_pre_gemm": "EpiLstmPre", "sep_gemm": "ALoadDensePReLU", "postproc_gemm": "taps_fold_kernel",
+                                  "ffn_ln_gemm": "ALoadColsT<false>, EpiBiasResLN"}.get(cls))
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: int = 0):
+    """A short, self-contained measurement of one forward configuration on this rank (N=1 legs of the headline line):
+    mixtures/s, whole-path fraction of the fp32-MFMA peak and its dominant kernel's figures."""
+    cfg, B_default, T, workload = CONFIGS[config]
+    B = batch or B_default
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(synthetic_state_dict(cfg, seed=0), dev))
+    inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123)
+    mix = torch.from_numpy(inp["mix"]).to(dev)
+    e1 = torch.from_numpy(inp["s1_embedding"]).to(dev) if not cfg.audio_only else None
+    e2 = torch.from_numpy(inp["s2_embedding"]).to(dev) if not cfg.audio_only else None
+    out = (torch.empty_like(mix), torch.empty_like(mix))
+    for _ in range(warmup):
+        eng.forward(mix, e1, e2, out=out)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward(mix, e1, e2, out=out)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    eng.profile(True)
+    eng.profile_reset()
+    for _ in range(psteps):
+        eng.forward(mix, e1, e2, out=out)
+    prof = eng.profile_read()
+    eng.profile(False)
+    rows = kernel_rows(cfg, eng, prof, psteps, B, T, dev)
+    tf = B / dt * eng.flops_per_mixture(T) / 1e12
+    res = {"workload": f"{workload}, batch={B}, T={T}", "value": round(B / dt, 3), "unit": "mixtures/sec",
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
+           "gflop_per_mixture": round(eng.flops_per_mixture(T) / 1e9, 1),
+           "whole_path_tflops": round(tf, 2), "whole_path_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+           "dominant_kernel": {k: rows[0][k] for k in ("class", "kernel", "launches_per_step", "launch_ms", "ms_per_step", "achieved", "frac")
+                               if k in rows[0]} if rows else None,
+           "kernels": [{k: r[k] for k in ("class", "ms_per_step", "frac")} for r in rows],
+           "outputs_finite": bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())}
+    del eng, out, mix, e1, e2
+    torch.cuda.empty_cache()
+    return res
+
+
+def optional_leg(name, fn, *a, **kw):
+    """Optional legs never cost the headline: an exception becomes {"error": ...} under the leg's key."""
+    try:
+        t0 = time.perf_counter()
+        res = fn(*a, **kw)
+        log(f"{name}: done in {time.perf_counter() - t0:.1f} s")
+        return res
+    except Exception as e:      # noqa: BLE001
+        log(f"{name} FAILED: {e!r}")
+        torch.cuda.empty_cache()
+        return {"error": f"{type(e).__name__}: {e}"[:500]}
+
+
+def split_experiment(eng, mix, e1, e2, out, B, steps, warmup, dev):
+    """Opt-in split-precision experiment (never the headline): option split_bf16, same workload, reported under its own key
+    with its agreement to the fp32 run."""
+    ref1, ref2 = out[0].clone(), out[1].clone()
+    eng.set_option("split_bf16", 1)
+    try:
+        o2 = (torch.empty_like(mix), torch.empty_like(mix))
+        for _ in range(max(2, warmup)):
+            eng.forward(mix, e1, e2, out=o2)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            eng.forward(mix, e1, e2, out=o2)
+        torch.cuda.synchronize(dev)
+        dts = (time.perf_counter() - t1) / steps
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(3):
+            eng.forward(mix, e1, e2, out=o2)
+        prof_s = eng.profile_read()
+        eng.profile(False)
+    finally:
+        eng.set_option("split_bf16", 0)
+
+    def agree(a, b):
+        return float(10 * torch.log10(a.double().pow(2).sum() / (a.double() - b.double()).pow(2).sum().clamp_min(1e-300)))
+    return {"what": "OPT-IN experiment, not the headline (option split_bf16): LSTM recurrence, pre-activation / FFN GEMMs and "
+                    "the attention block on bf16 MFMAs with every operand split into bf16 hi + lo (hi*hi + hi*lo + lo*hi, fp32 "
+                    "accumulation); head, tail, softmax, LayerNorm, cell update in fp32 as in the headline",
+            "kernels_ms_per_step": {k: round(v[0] / 3, 3) for k, v in prof_s.items() if v[1]},
+            "value": round(B / dts, 3), "unit": "mixtures/sec (this rank)", "ms_per_step": round(1e3 * dts, 4),
+            "agreement_db_vs_f32_run": round(min(agree(ref1, o2[0]), agree(ref2, o2[1])), 1), "budget_db": 51.0}
 
 
 def main():
@@ -254,6 +428,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the short configs[3] training-step measurement "
                     "that the default N=1 headline run appends as `train_step`")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[1] / configs[4] legs that the "
+                    "default N=1 headline run appends as `other_configs`")
+    ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision experiment leg")
     ap.add_argument("--pmc-run", action="store_true", help="warm-up + timed steps only (no per-kernel event pass, no isolated "
                     "pass, no CPU leg): the command rocprofv3 --pmc / --kernel-trace passes are taken over")
     args = ap.parse_args()
@@ -270,10 +447,11 @@ def main():
     torch.cuda.set_device(dev)
     cfg, B_default, T, workload = CONFIGS[args.config]
     B, Tv = args.batch or B_default, 50
+    headline = args.config == "dptn_av" and not args.pmc_run and env.world == 1 and not args.batch
     if args.config != "dptn_av" or args.pmc_run:
         args.no_cpu_baseline = True     # the CPU leg is only defined for the headline configuration
-    if args.config != "dptn_av" or args.pmc_run or env.world > 1:
-        args.no_train_step = True
+    if not headline:
+        args.no_train_step = args.no_other_configs = True
     if args.config.endswith("_train"):
         return bench_train(args, env, cfg, B, T, workload)
 
@@ -297,7 +475,9 @@ def main():
     torch.cuda.synchronize(dev)
     env.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = env.max_over_ranks(mine)
+    per_rank_s = env.gather_over_ranks(mine)
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     if args.pmc_run:
         if env.rank == 0:
@@ -313,7 +493,7 @@ def main():
     for _ in range(psteps):
         eng.forward(mix, e1, e2, out=out)
     prof = eng.profile_read()
-    # the dominant kernel once more with the two half-batches NOT overlapped (kernel alone on the chip)
+    # the recurrence once more with the two half-batches NOT overlapped (32-sequence-tile kernel alone on the chip)
     eng.set_option("overlap", 0)
     eng.profile_reset()
     try:
@@ -325,106 +505,46 @@ def main():
         prof_iso = None
     eng.set_option("overlap", 1)
     eng.profile(False)
+    for _ in range(2):
+        eng.forward(mix, e1, e2, out=out)          # `out` = the default (overlapped) path's result again
     finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())
 
-    # ---- opt-in split-precision experiment (never the headline): the LSTM recurrence on bf16 MFMAs with hi/lo-split
-    #      operands (option split_bf16), same workload, reported under its own key with its agreement to the fp32 run ----
     split = None
-    if not args.pmc_run:
-        ref1, ref2 = out[0].clone(), out[1].clone()
-        eng.set_option("split_bf16", 1)
-        o2 = (torch.empty_like(mix), torch.empty_like(mix))
-        for _ in range(max(2, args.warmup)):
-            eng.forward(mix, e1, e2, out=o2)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.forward(mix, e1, e2, out=o2)
-        torch.cuda.synchronize(dev)
-        dts = (time.perf_counter() - t1) / args.steps
-        eng.profile(True)
-        eng.profile_reset()
-        for _ in range(3):
-            eng.forward(mix, e1, e2, out=o2)
-        prof_s = eng.profile_read()
-        eng.profile(False)
-        eng.set_option("split_bf16", 0)
-
-        def agree(a, b):
-            return float(10 * torch.log10(a.double().pow(2).sum() / (a.double() - b.double()).pow(2).sum().clamp_min(1e-300)))
-        split = {"what": "OPT-IN experiment, not the headline (option split_bf16): LSTM recurrence, pre-activation / FFN GEMMs and "
-                         "the attention block on bf16 MFMAs with every operand split into bf16 hi + lo (hi*hi + hi*lo + lo*hi, fp32 "
-                         "accumulation); head, tail, softmax, LayerNorm, cell update in fp32 as in the headline",
-                 "kernels_ms_per_step": {k: round(v[0] / 3, 3) for k, v in prof_s.items() if v[1]},
-                 "value": round(B / dts, 3), "unit": "mixtures/sec (this rank)", "ms_per_step": round(1e3 * dts, 4),
-                 "agreement_db_vs_f32_run": round(min(agree(ref1, o2[0]), agree(ref2, o2[1])), 1),
-                 "budget_db": 51.0}
-        del ref1, ref2, o2
+    if not args.no_split:
+        split = optional_leg("split_bf16_experiment", split_experiment, eng, mix, e1, e2, out, B, args.steps, args.warmup, dev)
 
     if env.rank == 0:
         S, K, H = eng.chunks(T), cfg.chunk_size, cfg.hidden_dim
         M = B * S * K
-        # as run in the timed region: the batch is two overlapped halves, so one launch covers B/2 mixtures and shares
-        # the chip with the other half's GEMM / attention kernels
-        ms, n = prof["lstm_recurrence"]
-        lstm_ms = ms / max(n, 1)
-        launches_per_step = n / psteps
-        lstm_flops = float(M) * 2 * (2 * H * 4 * H) * (2 * cfg.num_blocks) / launches_per_step   # per launch: both directions, h W_hh^T
-        achieved = lstm_flops / (lstm_ms * 1e-3) / 1e12
+        rows = kernel_rows(cfg, eng, prof, psteps, B, T, dev)
+        dom = rows[0]
         iso = None
         if prof_iso is not None:
             ms_i, n_i = prof_iso["lstm_recurrence"]
             iso_ms = ms_i / max(n_i, 1)
             iso_tflops = float(M) * 2 * (2 * H * 4 * H) / (iso_ms * 1e-3) / 1e12
-            iso = {"note": "same kernel, whole batch in one launch, nothing else on the chip (option overlap=0)",
-                   "launch_ms": round(iso_ms, 4), "achieved": round(iso_tflops, 3),
+            iso = {"note": "lstm_recurrence_kernel (32-sequence tiles), whole batch in one launch, nothing else on the chip (option overlap=0)",
+                   "kernel": "lstm_recurrence_kernel", "launch_ms": round(iso_ms, 4), "achieved": round(iso_tflops, 3),
                    "frac": round(iso_tflops / PEAK_F32_MFMA_TFLOPS, 4)}
         kernels = {k: round(v[0] / psteps, 4) for k, v in prof.items()}
-        # which recurrence kernel those launches were (run_path in dptnav.hip: 16-sequence tiles when they fit the
-        # chip in one round, i.e. for half-batch launches; 32-sequence tiles otherwise)
-        b_launch = B * 2 * cfg.num_blocks / launches_per_step
-        ndir = 2 if cfg.bidir else 1
-        fits16 = all(-(-int(b_launch * n) // 16) * d <= torch.cuda.get_device_properties(dev).multi_processor_count
-                     for n, d in ((S, 2), (K, ndir)))
-        lstm_kernel = "lstm16_kernel" if fits16 else "lstm_recurrence_kernel"
-        # a recurrence launch occupies ONE CU per (direction, sequence tile) -- W_hh fills the CU's register file -- so
-        # beside `frac` (against the whole chip's peak, as the contract defines it) the share of the chip it can use
-        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        tile = 16 if fits16 else 32
-        wgs = sum(-(-int(b_launch * n) // tile) * d for n, d in ((S, 2), (K, ndir))) / 2.0    # mean of intra / inter
-        cu_share = min(1.0, wgs / n_cus)
-        if iso is not None:
-            iso["kernel"] = "lstm_recurrence_kernel"
-        # the other large kernel class, same convention (algorithmic FLOPs of one launch / its mean time as run): the
-        # fused attention block, which since round 2 also carries the FFN half of the previous path
-        other = None
-        if args.config == "dptn_av" and prof["attention"][1]:
-            a_ms, a_n = prof["attention"]
-            N_ = cfg.num_features
-            per_tok = 2 * N_ * 3 * N_ + 2 * N_ * N_ + 4 * ((K + S) / 2.0) * N_                  # QKV + out-proj + scores / PV
-            fused_ffn = prof["ffn_ln_gemm"][1] < a_n                                             # K6 rides in the block
-            per_tok += (2 * 2 * H * N_) * (1.0 - prof["ffn_ln_gemm"][1] / a_n) if fused_ffn else 0.0
-            a_flops = float(M) * (2 * cfg.num_blocks) * per_tok / (a_n / psteps)
-            a_tf = a_flops / (a_ms / a_n * 1e-3) / 1e12
-            other = {"kernel": "attn_block_kernel (in-proj + attention + out-proj + LN1" + (" + FFN/LN2 of the previous path)" if fused_ffn else ")"),
-                     "launch_ms": round(a_ms / a_n, 4), "launches_per_step": a_n / psteps, "achieved": round(a_tf, 3),
-                     "frac": round(a_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                     "note": "as run, beside the other sub-batch's recurrence (146 of 256 CUs)"}
         value = env.world * B * args.steps / elapsed
         # HBM traffic: from the committed PMC table (same configuration, batch and kernel only), never extrapolated
         tab = pmc_table(args.config)
-        traffic, traffic_unit, whole = None, "no PMC table for this configuration / kernel (profiles/r02_pmc_traffic.json)", None
-        if tab is not None and tab.get("batch") == B and tab.get("samples") == T:
-            krow = next((r for r in tab["kernels"] if r["name"].startswith(lstm_kernel)), None)
-            if krow is not None:
-                traffic = krow["hbm_bytes_per_launch"]
-                traffic_unit = (f"HBM bytes per launch, from {os.path.relpath(PMC_TABLE, ROOT)} (PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                                f"commit {tab.get('commit', '?')})")
+        tab_ok = tab is not None and tab.get("batch") == B and tab.get("samples") == T
+        whole = None
+        for r in rows:
+            krow = next((x for x in tab["kernels"] if r.get("pmc_match") and r["pmc_match"] in x["name"]), None) if tab_ok else None
+            r["traffic"] = krow["hbm_bytes_per_launch"] if krow else None
+            r.pop("pmc_match", None)
+        traffic_unit = (f"HBM bytes per launch, from {os.path.relpath(PMC_TABLE, ROOT)} (PMC FETCH_SIZE x2 + WRITE_SIZE, commit "
+                        f"{tab.get('commit', '?')})") if tab_ok else f"no PMC table for this configuration / batch ({os.path.relpath(PMC_TABLE, ROOT)})"
+        if tab_ok:
             min_bytes = eng.min_bytes_per_mixture(T) * B
             whole = {"bytes_per_step": tab["bytes_per_step"], "bytes_per_mixture": round(tab["bytes_per_step"] / B),
                      "ideal_bytes_per_mixture": round(min_bytes / B), "ratio_to_ideal": round(tab["bytes_per_step"] / min_bytes, 2),
                      "avg_tb_per_s": round(tab["bytes_per_step"] / (elapsed / args.steps) / 1e12, 3),
-                     "source": f"{os.path.relpath(PMC_TABLE, ROOT)} (sum over kernels x launches per step, commit {tab.get('commit', '?')})"}
+                     "source": f"{os.path.relpath(PMC_TABLE, ROOT)} (sum over kernels x launches per step, commit {tab.get('commit', '?')}; "
+                               f"{tab.get('corrections', '')})"}
         line = {
             "metric": "mixtures/sec (2-spk, 4 s @ 8 kHz) DPTN-AV forward" if args.config == "dptn_av"
                       else f"mixtures/sec {args.config} forward",
@@ -434,14 +554,14 @@ def main():
             "config": {"workload": f"{workload}, batch={B} per GPU, T={T}, random-init weights (numpy seed 0)",
                        "batch_per_gpu": B, "samples": T, "tokens_per_mixture": S * K,
                        "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": lstm_kernel, "achieved": round(achieved, 3),
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": traffic_unit,
-                         "algorithmic_bytes": int(M * 2 * cfg.num_blocks / launches_per_step) * (8 * H + 2 * H) * 4,
-                         "launch_ms": round(lstm_ms, 4), "flops_per_launch": lstm_flops,
-                         "cus_occupied": round(wgs, 1), "frac_of_occupied_cus": round(achieved / (PEAK_F32_MFMA_TFLOPS * cu_share), 4),
-                         "launches_per_step": launches_per_step,
-                         "isolated": iso, "second_kernel": other,
+            "roofline": {"bound": "mfma", "kernel": dom["kernel"], "class": dom["class"], "achieved": dom["achieved"],
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+                         "traffic": dom["traffic"], "traffic_unit": traffic_unit,
+                         "launch_ms": dom["launch_ms"], "flops_per_launch": dom["flops_per_launch"],
+                         "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
+                         "dominant_by": "largest device time per step among the kernel classes of THIS run (kernels_ms_per_step)",
+                         "kernels": rows,
+                         "isolated": iso,
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},
@@ -449,14 +569,21 @@ def main():
             "split_bf16_experiment": split,
             "kernels_ms_per_step": kernels,
             "outputs_finite": finite,
+            "backend": env.backend, "rccl_ranks": env.backend_world() if env.backend == "nccl" else 0,
+            "per_rank_mixtures_per_sec": [round(B * args.steps / t, 3) for t in per_rank_s],
         }
+        del eng, out, mix, e1, e2
+        torch.cuda.empty_cache()
+        if not args.no_other_configs:
+            line["other_configs"] = {
+                "dptn_audio": optional_leg("other_configs.dptn_audio", forward_leg, "dptn_audio", dev, steps=10, warmup=3, psteps=3),
+                "dprnn_av": optional_leg("other_configs.dprnn_av", forward_leg, "dprnn_av", dev, steps=3, warmup=1, psteps=1)}
         if not args.no_train_step:
-            del eng, out
-            torch.cuda.empty_cache()
-            line["train_step"] = train_step_leg(cfg, dev, T)
+            line["train_step"] = optional_leg("train_step", train_step_leg, cfg, dev, T)
         if env.world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd)
-            line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)
+            line["cpu_baseline"] = optional_leg("cpu_baseline", cpu_baseline, cfg, sd)
+            if "value" in line["cpu_baseline"]:
+                line["speedup_vs_cpu_baseline"] = round(value / max(line["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(line), flush=True)
     env.close()
 

@@ -35,17 +35,38 @@ def _owner(params) -> "nn.Module":
     return model
 
 
-def _flat_grad(model: "nn.Module") -> torch.Tensor:
+def _flat_grad_problem(model: "nn.Module") -> Optional[str]:
+    """None when every parameter's .grad is the matching view of `model._flat_grad` (the fused clip / step may run on the
+    flat tensor); otherwise the reason why not, naming the first offending parameter."""
     flat = getattr(model, "_flat_grad", None)
     if flat is None:
-        raise RuntimeError("no gradient yet: run loss.backward() through the model first")
+        return "no gradient yet: run loss.backward() through the model first"
     eng = model._engine
     base, offs = flat.data_ptr(), eng._grad_offsets
     for key, p in model.named_parameters():
-        if p.grad is None or p.grad.data_ptr() != base + 4 * offs[key]:
-            raise RuntimeError(f"{key}.grad is not a view of the model's flat gradient (gradient accumulation over several "
-                               f"backward passes is not supported by the fused step: call optimizer.zero_grad() every step)")
-    return flat
+        if not p.requires_grad:
+            return (f"{key} is frozen (requires_grad=False): the fused clip / optimizer step covers ALL parameters of the "
+                    f"model; use torch.nn.utils.clip_grad_norm_ and torch.optim.AdamW on the trainable subset")
+        if p.grad is None:
+            return (f"{key}.grad is None (zero_grad(set_to_none=True) after the backward, or the parameter did not take part "
+                    f"in it): nothing to clip / step")
+        if p.grad.data_ptr() != base + 4 * offs[key]:
+            return (f"{key}.grad is not a view of the model's flat gradient (it was accumulated over several backward passes, "
+                    f"or kept by zero_grad(set_to_none=False)): the fused clip / step needs zero_grad() with its default "
+                    f"set_to_none=True before every backward")
+    return None
+
+
+def _flat_grad(model: "nn.Module") -> torch.Tensor:
+    why = _flat_grad_problem(model)
+    if why is not None:
+        raise RuntimeError(why)
+    return model._flat_grad
+
+
+def flat_grad_or_none(model: "nn.Module") -> Optional[torch.Tensor]:
+    """The flat gradient tensor if the fused clip / step can run on it, else None (train_step then takes the stock path)."""
+    return None if _flat_grad_problem(model) is not None else model._flat_grad
 
 
 def clip_grad_norm_(parameters: Union["nn.Module", Iterable[torch.Tensor]], max_norm: Optional[float]) -> torch.Tensor:

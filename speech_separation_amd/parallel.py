@@ -35,11 +35,14 @@ class DistEnv:
     world: int
     device: torch.device
     backend: Optional[str]
+    active: bool = False      # a process group exists: collectives go through torch.distributed (always when world > 1)
 
     @classmethod
     def from_environ(cls, expected_world: Optional[int] = None, backend: Optional[str] = None,
-                     device: Optional[str] = None) -> "DistEnv":
-        """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them)."""
+                     device: Optional[str] = None, force_init: bool = False) -> "DistEnv":
+        """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets them).
+        `force_init`: create the process group even for ONE rank, so that every collective of this class and the
+        gradient all-reduce really go through the backend (RCCL on a one-GPU box: tests/test_gpu_parallel.py)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -49,7 +52,8 @@ class DistEnv:
         if device is None:
             device = f"cuda:{local}"
         dev = torch.device(device)
-        if world > 1:
+        active = world > 1 or force_init
+        if active:
             import torch.distributed as dist
             backend = backend or ("nccl" if dev.type == "cuda" else "gloo")   # "nccl" IS RCCL on ROCm
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -59,11 +63,11 @@ class DistEnv:
                 dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         else:
             backend = None
-        return cls(rank, local, world, dev, backend)
+        return cls(rank, local, world, dev, backend, active)
 
     # -- collectives (all trivially local when world == 1) -------------------------------------------
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             import torch.distributed as dist
             if self.backend == "nccl":
                 dist.barrier(device_ids=[self.device.index])
@@ -71,7 +75,7 @@ class DistEnv:
                 dist.barrier()
 
     def _reduce(self, values: Sequence[float], op) -> List[float]:
-        if self.world == 1:
+        if not self.active:
             return list(values)
         import torch.distributed as dist
         t = torch.tensor(list(values), dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
@@ -86,8 +90,25 @@ class DistEnv:
         import torch.distributed as dist
         return self._reduce(values, dist.ReduceOp.SUM)
 
+    def gather_over_ranks(self, x: float) -> List[float]:
+        """[x of rank 0, x of rank 1, ...] on every rank (one all_gather of a float64 scalar)."""
+        if not self.active:
+            return [float(x)]
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [float(o.cpu()[0]) for o in out]
+
+    def backend_world(self) -> int:
+        """World size as the BACKEND sees it (dist.get_world_size()), 0 without a process group."""
+        if not self.active:
+            return 0
+        import torch.distributed as dist
+        return int(dist.get_world_size())
+
     def close(self):
-        if self.world > 1:
+        if self.active:
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()

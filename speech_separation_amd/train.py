@@ -13,7 +13,8 @@ reference's clip does on the full gradient (base_trainer.py:383-391).  The retur
 DEVICE tensors: reading them (logging, trainer.py:55) is the caller's only synchronisation, not one per step.
 PIT is batch level: every rank resolves the permutation on its own 16 mixtures (SURVEY.md 8e caveat).
 Stock torch.optim optimizers and torch.nn.utils.clip_grad_norm_ keep working (the parameters and .grad are ordinary
-tensors); `train_step` picks the fused clip whenever the model is a drop-in with a flat gradient.
+tensors); `train_step` picks the fused clip whenever every `.grad` is a view of the drop-in's flat gradient and torch's otherwise
+(frozen parameters, gradient accumulation).
 """
 from __future__ import annotations
 
@@ -23,14 +24,14 @@ import torch
 from torch import nn
 
 from .metrics import SiSNRWavLoss  # noqa: F401  (re-export: the criterion of the training step)
-from .optim import FusedAdamW, clip_grad_norm_  # noqa: F401
+from .optim import FusedAdamW, clip_grad_norm_, flat_grad_or_none  # noqa: F401
 from .parallel import DistEnv
 
 
 def allreduce_gradients(model: nn.Module, env: Optional[DistEnv]) -> str:
     """Average the gradients over ranks with ONE collective on a flat bucket (no-op for a single process).  Returns which
     way it went: "single", "flat-in-place" (the drop-in's own flat gradient tensor, no copies) or "flat-copy"."""
-    if env is None or env.world == 1:
+    if env is None or not env.active:
         return "single"
     import torch.distributed as dist
     grads = [p.grad for p in model.parameters() if p.grad is not None]
@@ -61,10 +62,12 @@ def train_step(model: nn.Module, batch: Dict[str, object], criterion, optimizer,
     allreduce_gradients(model, env)
     norm = None
     if max_grad_norm is not None:
-        if getattr(model, "_flat_grad", None) is not None:
-            norm = clip_grad_norm_(model, max_grad_norm)                                   # two launches on the flat tensor
+        # fused clip (two launches on the flat tensor) only when every .grad is a view of it; frozen parameters
+        # (train.py:51 passes filter(requires_grad)), accumulated gradients or foreign modules take torch's clip
+        if getattr(model, "_flat_grad", None) is not None and flat_grad_or_none(model) is not None:
+            norm = clip_grad_norm_(model, max_grad_norm)
         else:
-            norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+            norm = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], max_grad_norm)
     optimizer.step()
     if lr_scheduler is not None:
         lr_scheduler.step()

@@ -348,7 +348,7 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     parameter that the imported reference produced with `model.train(); outputs = model(**batch); SiSNRWavLoss;
     loss.backward()` (trainer.py:40-47, ss_losses.py:21-26,96-130, dptn_wav.py:171-194; dropout 0.0 -- tools/gen_golden.py).
     Here the same step runs through the drop-in nn.Module (dptnav_train_forward / dptnav_train_backward) and the device
-    loss (dptnav_pit_sisnr_loss).  `copies` = 16 repeats the fixture's one mixture over the batch of config 4
+    loss (dptnav_pit_sisnr_loss); the truth is the same reference step run in fp64.  `copies` = 16 repeats the fixture's one mixture over the batch of config 4
     (B=16 x T=32000, 6 blocks): the batch mean of 16 identical terms is the single term, so loss and gradients must
     reproduce the B=1 reference numbers while every kernel runs at its full BASELINE size (two halves, two streams)."""
     from speech_separation_amd import DPTNAVWavEncDec
@@ -372,13 +372,17 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     loss = SiSNRWavLoss()(**batch)["loss"]
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(z["val.loss"])) < 1e-4 * abs(float(z["val.loss"])), (float(loss), float(z["val.loss"]))
+    assert abs(float(loss) - float(z["val.loss64"])) < 1e-5 * abs(float(z["val.loss64"])), (float(loss), float(z["val.loss64"]))
     for k in ("s1_pred", "s2_pred"):        # the training forward reproduces the reference's train-mode outputs, every row
         for r in range(0, B * copies, B):
             assert O.agreement_db(batch[k][r:r + B].detach().cpu().numpy(), z["tap." + k]) > 80, (k, r)
     grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
-    worst_db, worst_norm = reference_gradient_report(z, grads)
-    assert worst_db[0] > 60, worst_db
+    # truth = the reference's step run in fp64; a parameter must agree to 60 dB, or to within 3 dB of what the reference's
+    # own fp32 step achieves for it (bias / LayerNorm gradients, sums over 10^5..10^6 tokens, are 50-60 dB there)
+    fails, worst_db, worst_norm = reference_gradient_report(z, grads, floor_db=60.0, margin_db=3.0)
+    print(f"{name} x{copies} tile {lstm_tile}: worst parameter {worst_db[1]} {worst_db[0]:.1f} dB (the reference's fp32 step: "
+          f"{float(z['ref32db.' + worst_db[1]]):.1f} dB), worst norm error {worst_norm[0]:.2e} ({worst_norm[1]})")
+    assert not fails, fails[:8]
     assert worst_norm[0] < 1e-3, worst_norm
     total = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
     assert abs(total - float(z["val.grad_norm"])) < 1e-4 * float(z["val.grad_norm"])

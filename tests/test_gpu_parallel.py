@@ -99,3 +99,73 @@ def test_bench_launches_its_own_ranks(config):
     assert np.isfinite(line["value"]) and line["value"] > 0
     # whole-job throughput counts both ranks' mixtures
     assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
+
+
+def _rccl_worker(port, q):
+    """ONE rank, but a real process group over the real backend ("nccl" = RCCL on ROCm): what every rank of the 8-GPU
+    launch executes, minus the peers."""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import torch.distributed as dist
+        from speech_separation_amd import DPTNAVWavEncDec
+        from speech_separation_amd.parallel import DistEnv
+        from speech_separation_amd.spec import synthetic_inputs, synthetic_state_dict
+        from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, allreduce_gradients, train_step
+        env = DistEnv.from_environ(expected_world=1, force_init=True)           # init_process_group("nccl", device_id=cuda:0)
+        out = {"backend": dist.get_backend(), "active": env.active, "backend_world": env.backend_world()}
+        dev = env.device
+        torch.cuda.set_device(dev)
+        env.barrier()                                                            # dist.barrier(device_ids=[0]) over RCCL
+        out["max"] = env.max_over_ranks(3.25)                                    # float64 MAX all-reduce on the device
+        out["sum"] = env.sum_over_ranks([1.5, 2.5])
+        out["gather"] = env.gather_over_ranks(7.0)
+        model = DPTNAVWavEncDec(num_features=128, video_emb_size=512, hidden_video=128, kernel_size_enc=7, hidden_dim=128,
+                                num_blocks=1, chunk_size=150, step_size=75, num_heads=4, dropout=0.0, bidir=True)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+        model = model.to(dev).train()
+        inp = synthetic_inputs(model.cfg, B=4, T=4000, Tv=50, seed=40)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+        batch.update(model(**batch))
+        SiSNRWavLoss()(**batch)["loss"].backward()
+        # NO synchronisation between the backward (library-internal streams, joined to the caller's stream) and the
+        # asynchronous device collective: the ordering contract of dptnav_train_backward is what is under test
+        flat = model._flat_grad
+        local = flat.clone()
+        out["how"] = allreduce_gradients(model, env)
+        torch.cuda.synchronize(dev)
+        out["err"] = float((flat - local).abs().max())
+        out["scale"] = float(local.abs().max())
+        # and twice through the whole step (zero_grad .. all-reduce .. clip .. FusedAdamW) with the group active
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(2):
+            b = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+            st = train_step(model, b, SiSNRWavLoss(), opt, 10.0, env=env)
+            losses.append((float(st["loss"]), float(st["grad_norm"])))
+        out["losses"] = losses
+        env.close()
+        q.put(out)
+    except Exception as e:      # noqa: BLE001 -- reported to the parent, which fails the test with the text
+        import traceback
+        q.put({"error": f"{e!r}\n{traceback.format_exc()}"})
+
+
+def test_rccl_process_group_collectives_and_gradient_allreduce():
+    """The RCCL branch itself: a world-1 process group over the real backend in a spawned child --
+    DistEnv.barrier / max_over_ranks / sum_over_ranks / gather_over_ranks and train.allreduce_gradients on the real
+    model's flat gradient right after loss.backward()."""
+    assert torch.cuda.is_available()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert "error" not in res, res.get("error")
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl" and res["active"] and res["backend_world"] == 1
+    assert res["max"] == 3.25 and res["sum"] == [1.5, 2.5] and res["gather"] == [7.0]
+    assert res["how"] == "flat-in-place"
+    assert res["scale"] > 0 and res["err"] == 0.0            # SUM over one rank, / 1: the local gradient, bit for bit
+    assert all(np.isfinite(v) for pair in res["losses"] for v in pair) and res["losses"][1][0] < res["losses"][0][0]

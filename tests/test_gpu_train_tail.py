@@ -175,3 +175,42 @@ def test_training_step_enqueues_without_host_synchronisation(dev):
     losses = [float(first["loss"])] + [float(s["loss"]) for s in stats]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert all(s["grad_norm"].device.type == "cuda" and float(s["grad_norm"]) > 0 for s in stats)
+
+
+def test_train_step_with_a_frozen_parameter_or_kept_gradients_takes_the_stock_clip(dev):
+    """the reference builds its optimizer from filter(requires_grad) (train.py:51).  With a frozen parameter,
+    or with zero_grad(set_to_none=False), the parameters' .grad are not all views of the flat gradient: train_step must
+    fall back to torch's clip (and a stock optimizer keeps working) instead of raising; the fused entry points say WHY
+    they cannot run."""
+    from speech_separation_amd.optim import FusedAdamW, clip_grad_norm_
+    from speech_separation_amd.train import SiSNRWavLoss, train_step
+    model = small_model(dev)
+    model.gate.requires_grad_(False)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainable, lr=1e-3)
+    inp = synthetic_inputs(model.cfg, B=2, T=2000, Tv=50, seed=8)
+    gate0 = model.gate.detach().clone()
+    losses = []
+    for _ in range(3):
+        st = train_step(model, {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}, SiSNRWavLoss(), opt, 10.0)
+        losses.append(float(st["loss"]))
+        assert float(st["grad_norm"]) > 0
+    assert model.gate.grad is None and torch.equal(model.gate.detach(), gate0)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    with pytest.raises(RuntimeError, match="frozen"):
+        clip_grad_norm_(model, 10.0)
+    with pytest.raises(RuntimeError, match="ALL parameters"):
+        FusedAdamW(trainable, lr=1e-3).step()
+
+    # gradients kept across steps (set_to_none=False): autograd accumulates into the OLD views, not the step's flat tensor
+    model2 = small_model(dev)
+
+    class KeepGrads(torch.optim.AdamW):
+        def zero_grad(self, set_to_none=True):
+            super().zero_grad(set_to_none=False)
+    opt2 = KeepGrads(model2.parameters(), lr=1e-3)
+    for _ in range(2):
+        st = train_step(model2, {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}, SiSNRWavLoss(), opt2, 10.0)
+        assert np.isfinite(float(st["loss"])) and float(st["grad_norm"]) > 0
+    with pytest.raises(RuntimeError, match="not a view"):
+        clip_grad_norm_(model2, 10.0)

@@ -139,33 +139,36 @@ def test_convtasnet_stock_composition_matches_reference():
         assert out[k].shape == (2, 4000) and O.agreement_db(out[k].numpy(), z[k]) > 100
 
 
-def reference_gradient_report(z, grads):
+def reference_gradient_report(z, grads, floor_db=60.0, margin_db=3.0):
     """Compare {state_dict key: gradient array} with a tests/golden/grad_*.npz record of the REFERENCE's loss.backward()
-    (tools/gen_golden.py::reference_gradients): -> (worst agreement in dB over parameters, its key, worst relative norm
-    error, its key).  Small tensors are stored whole, big ones as every `stride`-th element."""
+    (tools/gen_golden.py::reference_gradients; truth = the reference run in fp64, small tensors stored whole, big ones as
+    every `stride`-th element).  A parameter passes when it agrees with the truth to `floor_db`, or to within `margin_db`
+    of what the reference's OWN fp32 run achieves for it (`ref32db.*`: sums over 10^5..10^6 tokens are 50-60 dB in fp32).
+    -> (failures [(key, dB, required dB)], worst dB, worst relative norm error)."""
     stride, full_below = int(z["stride"]), int(z["full_below"])
-    worst_db, worst_norm = (1e9, None), (0.0, None)
     keys = [k[5:] for k in z if k.startswith("grad.")]
     assert sorted(keys) == sorted(grads), set(keys) ^ set(grads)
+    fails, worst_db, worst_norm = [], (1e9, None), (0.0, None)
     for k in keys:
         g = np.asarray(grads[k], dtype=np.float64)
         want = z["grad." + k]
         got = g.reshape(want.shape) if g.size <= full_below else g.reshape(-1)[::stride]
         db = O.agreement_db(got, want)
+        need = min(floor_db, float(z["ref32db." + k]) - margin_db)
+        if db < need:
+            fails.append((k, round(db, 1), round(need, 1)))
+        worst_db = min(worst_db, (db, k))
         nrm = float(np.sqrt((g ** 2).sum()))
-        rel = abs(nrm - float(z["norm." + k])) / max(float(z["norm." + k]), 1e-30)
-        if db < worst_db[0]:
-            worst_db = (db, k)
-        if rel > worst_norm[0]:
-            worst_norm = (rel, k)
-    return worst_db, worst_norm
+        worst_norm = max(worst_norm, (abs(nrm - float(z["norm." + k])) / max(float(z["norm." + k]), 1e-30), k))
+    return fails, worst_db, worst_norm
 
 
 @pytest.mark.parametrize("name", ["grad_tiny_av", "grad_mid_av"])
 def test_stock_autograd_matches_reference_gradients(golden, name):
-    """The gradient oracle of the GPU backward tests (torch.autograd through oracle/torch_stock.py + SiSNRWavLossTorch)
-    reproduces what the REFERENCE's own training step produced: loss (ss_losses.py:21-26,96-130) and d loss / d every
-    parameter after loss.backward() (trainer.py:40-47), captured by tools/gen_golden.py from the imported reference."""
+    """The gradient oracle of the GPU backward tests (torch.autograd through oracle/torch_stock.py + SiSNRWavLossTorch, in
+    fp64) reproduces what the REFERENCE's own training step produced in fp64: loss (ss_losses.py:21-26,96-130) and
+    d loss / d every parameter after loss.backward() (trainer.py:40-47), captured by tools/gen_golden.py from the imported
+    reference.  In fp32 the port's loss equals the reference's fp32 loss."""
     import torch
     from oracle.torch_stock import SiSNRWavLossTorch, StockDPTN
     cfg, z = golden(name)
@@ -174,17 +177,23 @@ def test_stock_autograd_matches_reference_gradients(golden, name):
     sd = synthetic_state_dict(cfg, seed=wseed)
     assert weights_digest(sd) == str(z["digest"])
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=Tv, seed=iseed)
+    out32 = StockDPTN(cfg, sd)(**{k: torch.from_numpy(v) for k, v in inp.items()})
+    loss32 = SiSNRWavLossTorch()(**{**{k: torch.from_numpy(v) for k, v in inp.items()}, **out32})["loss"]
+    assert abs(float(loss32) - float(z["val.loss"])) < 1e-5 * abs(float(z["val.loss"]))
+    for k in ("s1_pred", "s2_pred"):        # train mode with dropout 0 == eval mode
+        assert O.agreement_db(out32[k].numpy(), z["tap." + k]) > 100
     ref = StockDPTN(cfg, sd)
-    ref.sd = {k: v.requires_grad_(True) for k, v in ref.sd.items()}
+    ref.sd = {k: v.double().requires_grad_(True) for k, v in ref.sd.items()}
+    ref.paths = [(pre, m.double(), r.double()) for pre, m, r in ref.paths]
     for _, m, r in ref.paths:
         for p in list(m.parameters()) + list(r.parameters()):
             p.requires_grad_(True)
-    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
+    batch = {k: torch.from_numpy(v).double() for k, v in inp.items()}
     with torch.enable_grad():
         batch.update(StockDPTN.__call__.__wrapped__(ref, **batch))
         loss = SiSNRWavLossTorch()(**batch)["loss"]
         loss.backward()
-    assert abs(float(loss) - float(z["val.loss"])) < 1e-4 * abs(float(z["val.loss"]))
+    assert abs(float(loss.detach()) - float(z["val.loss64"])) < 1e-9 * abs(float(z["val.loss64"]))
     grads = {}
     for pre, m, r in ref.paths:
         grads[pre + "mha.in_proj_weight"], grads[pre + "mha.in_proj_bias"] = m.in_proj_weight.grad, m.in_proj_bias.grad
@@ -194,6 +203,7 @@ def test_stock_autograd_matches_reference_gradients(golden, name):
     for k, v in ref.sd.items():
         if k not in grads:
             grads[k] = v.grad
-    worst_db, worst_norm = reference_gradient_report(z, {k: v.numpy() for k, v in grads.items()})
-    assert worst_db[0] > 80, worst_db
-    assert worst_norm[0] < 1e-3, worst_norm
+    fails, worst_db, worst_norm = reference_gradient_report(z, {k: v.numpy() for k, v in grads.items()}, floor_db=120.0,
+                                                            margin_db=-1e9)
+    assert not fails, fails[:5]
+    assert worst_norm[0] < 1e-7, worst_norm

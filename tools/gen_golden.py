@@ -128,25 +128,37 @@ GRAD_FULL_BELOW = 4096
 
 def reference_gradients(dptn_wav, losses, cfg: DPTNConfig, sd, inp):
     """The reference's OWN training step up to loss.backward() (trainer.py:38-47): model.train(), outputs = model(**batch),
-    SiSNRWavLoss (ss_losses.py:21-26,96-130), loss.backward().  dropout must be 0.0 for a deterministic fixture (train-mode
-    attention dropout is a torch RNG stream); nn.LSTM(dropout=1) is a no-op for one layer (dptn.py:23-29)."""
+    SiSNRWavLoss (ss_losses.py:21-26,96-130), loss.backward() -- run twice: in fp32 as the trainer runs it, and with the
+    same modules cast to fp64 (`model.double()`, the reference's code, exact to ~1e-15).  The fp64 run's gradients are
+    the fixture's truth; the fp32 run's agreement with them, per parameter (`ref32db.*`), is the REFERENCE'S OWN rounding
+    noise (bias / LayerNorm gradients are sums over 10^5..10^6 tokens: 50-60 dB in fp32).  dropout must be 0.0 for a
+    deterministic fixture (train-mode attention dropout is a torch RNG stream); nn.LSTM(dropout=1) is a
+    no-op for one layer (dptn.py:23-29)."""
     assert cfg.dropout == 0.0
-    model = build_reference(dptn_wav, cfg, sd).train()
-    batch = {k: torch.from_numpy(v) for k, v in inp.items()}
-    model.zero_grad()
-    with torch.enable_grad():
-        batch.update(model(mix_spectrogram=torch.zeros(1), **batch))
-        loss = losses.SiSNRWavLoss()(**batch)["loss"]
-        loss.backward()
-    out = {"val.loss": np.float64(loss.item()), "tap.s1_pred": batch["s1_pred"].detach().numpy(),
-           "tap.s2_pred": batch["s2_pred"].detach().numpy()}
-    total = 0.0
-    for k, p in model.named_parameters():
-        g = p.grad.detach().numpy()
-        out[f"norm.{k}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
-        total += float(out[f"norm.{k}"]) ** 2
-        out[f"grad.{k}"] = g.copy() if g.size <= GRAD_FULL_BELOW else subsample(g, GRAD_STRIDE)
-    out["val.grad_norm"] = np.float64(np.sqrt(total))      # what clip_grad_norm_ sees (base_trainer.py:383-391)
+    from oracle import dptn_oracle as O
+
+    def run(dtype):
+        model = build_reference(dptn_wav, cfg, sd).train().to(dtype)
+        batch = {k: torch.from_numpy(v).to(dtype) for k, v in inp.items()}
+        model.zero_grad()
+        with torch.enable_grad():
+            batch.update(model(mix_spectrogram=torch.zeros(1), **batch))
+            loss = losses.SiSNRWavLoss()(**batch)["loss"]
+            loss.backward()
+        return (float(loss.item()), {k: p.grad.detach().double().numpy() for k, p in model.named_parameters()},
+                {k: batch[k].detach().numpy() for k in ("s1_pred", "s2_pred")})
+
+    loss32, g32, pred32 = run(torch.float32)
+    loss64, g64, _ = run(torch.float64)
+    out = {"val.loss": np.float64(loss32), "val.loss64": np.float64(loss64), "tap.s1_pred": pred32["s1_pred"],
+           "tap.s2_pred": pred32["s2_pred"]}
+    for k, g in g64.items():
+        out[f"norm.{k}"] = np.float64(np.sqrt((g ** 2).sum()))
+        out[f"ref32db.{k}"] = np.float64(O.agreement_db(g32[k], g))
+        out[f"grad.{k}"] = (g.copy() if g.size <= GRAD_FULL_BELOW else subsample(g, GRAD_STRIDE)).astype(np.float32)
+    # what clip_grad_norm_ sees (base_trainer.py:383-391), exact and as the reference's fp32 step computes it
+    out["val.grad_norm"] = np.float64(np.sqrt(sum(float((g ** 2).sum()) for g in g64.values())))
+    out["val.grad_norm32"] = np.float64(np.sqrt(sum(float((g ** 2).sum()) for g in g32.values())))
     return out
 
 
@@ -167,7 +179,8 @@ def gradient_fixtures(dptn_wav, losses, only):
                             shape=np.array([shp["B"], shp["T"], shp["Tv"]]), seeds=np.array([wseed, iseed]),
                             stride=np.array(GRAD_STRIDE), full_below=np.array(GRAD_FULL_BELOW),
                             digest=np.array(weights_digest(sd)), **rec)
-        print(name, "loss", rec["val.loss"], "grad norm", rec["val.grad_norm"])
+        print(name, "loss", rec["val.loss"], rec["val.loss64"], "grad norm", rec["val.grad_norm"], rec["val.grad_norm32"],
+              "reference fp32 vs fp64, worst parameter:", min((float(v), k) for k, v in rec.items() if k.startswith("ref32db.")))
 
 
 def main():
