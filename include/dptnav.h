@@ -159,7 +159,9 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
  *   (src/trainer/trainer.py:47): given d loss / d s1_pred and d loss / d s2_pred it WRITES the gradient of every
  *   parameter into the buffers bound with dptnav_bind_grads.  The loss itself (src/loss/ss_losses.py), gradient
  *   clipping and the optimizer stay the reference's own PyTorch code (speech_separation_amd/model.py wraps these two
- *   calls in a torch.autograd.Function).  Train-mode attention dropout: options dropout_ppm / dropout_seed below. */
+ *   calls in a torch.autograd.Function).  Train-mode attention dropout: options dropout_ppm / dropout_seed below.
+ *   Limit of the training step (not of inference): Tv <= 256 video frames per mixture (> 10 s of 25 fps lip embeddings);
+ *   the size queries return 0 and dptnav_train_forward fails with DPTNAV_ERR_INVALID BEFORE launching anything. */
 size_t dptnav_train_tape_bytes(dptnav_handle h, int B, int64_t T, int Tv);
 size_t dptnav_train_workspace_bytes(dptnav_handle h, int B, int64_t T, int Tv);
 int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, const float* e2, int B, int64_t T, int Tv,

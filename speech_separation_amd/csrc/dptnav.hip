@@ -113,26 +113,35 @@ struct dptnav_ctx {
     }
     return 0;
   }
-  int ensure_streams() {
-    if (streams[0]) return 0;
+  bool streams_ready = false;          // set LAST by ensure_streams: internal streams / events exist, all of them
+  void release_streams() {             // destroys whatever exists (a partial creation included) and forgets it
+    for (int i = 0; i < NSTREAMS; ++i) {
+      if (streams[i]) { hipStreamDestroy(streams[i]); streams[i] = nullptr; }
+      if (ev_join[i]) { hipEventDestroy(ev_join[i]); ev_join[i] = nullptr; }
+      if (i < 2 && ev_lstm[i]) { hipEventDestroy(ev_lstm[i]); ev_lstm[i] = nullptr; }
+    }
+    if (ev_fork) { hipEventDestroy(ev_fork); ev_fork = nullptr; }
     for (int i = 0; i < 2; ++i)
       for (int k = 0; k < 4; ++k)
-        if (hipEventCreateWithFlags(&ev_side[i][k], hipEventDisableTiming) != hipSuccess) {
-          err = "cannot create internal streams/events";
-          return 4;
-        }
-    for (int i = 0; i < NSTREAMS; ++i) {
-      if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) != hipSuccess ||
-          (i < 2 && hipEventCreateWithFlags(&ev_lstm[i], hipEventDisableTiming) != hipSuccess)) {
-        err = "cannot create internal streams/events";
-        return 4;
-      }
+        if (ev_side[i][k]) { hipEventDestroy(ev_side[i][k]); ev_side[i][k] = nullptr; }
+    streams_ready = false;
+  }
+  int ensure_streams() {               // all or nothing: a failure leaves no half-made set behind for the next call
+    if (streams_ready) return 0;
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i)
+      for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(&ev_side[i][k], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < NSTREAMS && ok; ++i)
+      ok = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming) == hipSuccess &&
+           (i >= 2 || hipEventCreateWithFlags(&ev_lstm[i], hipEventDisableTiming) == hipSuccess);
+    ok = ok && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      release_streams();
+      return fail(DPTNAV_ERR_HIP, "cannot create internal streams/events");
     }
-    if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) {
-      err = "cannot create fork event";
-      return 4;
-    }
+    streams_ready = true;
     return 0;
   }
   std::vector<ProfRec> prof_pending;
@@ -803,6 +812,7 @@ struct BwdRun {
   bool wg_pending[3] = {false, false, false};
   int dg_sel = 0, side_slot = 0;
   unsigned* take_queue_side(int n) {   // own counters: the main stream re-zeroes its region while side launches may be in flight
+    if (side_slot + n > QUEUE_SLOTS) return nullptr;        // the caller fails the launch (as launch_gemm does for `slot`)
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue2) + side_slot;
     side_slot += n;
     return q;
@@ -1035,8 +1045,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (side) {
       if (hipEventRecord(br.ev_bptt, st) != hipSuccess || hipStreamWaitEvent(br.side, br.ev_bptt, 0) != hipSuccess)
         return c->fail(DPTNAV_ERR_HIP, "side stream fork");
-      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, br.side, br.ws + br.pl.slab2,
-                                           br.take_queue_side(4)))
+      unsigned* side_q = br.take_queue_side(4);
+      if (!side_q) return c->fail(DPTNAV_ERR_INVALID, "d w_ih + d w_hh: side-stream ticket counters exhausted");
+      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, br.side, br.ws + br.pl.slab2, side_q))
         return rc;
       if (hipEventRecord(br.ev_wg[br.dg_sel], br.side) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream record");
       br.wg_pending[br.dg_sel] = true;
@@ -1384,16 +1395,8 @@ void dptnav_destroy(dptnav_handle h) {
   if (!h) return;
   for (ProfRec& r : h->prof_pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (hipEvent_t e : h->prof_pool) hipEventDestroy(e);
-  for (int i = 0; i < dptnav_ctx::NSTREAMS; ++i) {
-    if (h->streams[i]) hipStreamDestroy(h->streams[i]);
-    if (h->ev_join[i]) hipEventDestroy(h->ev_join[i]);
-    if (i < 2 && h->ev_lstm[i]) hipEventDestroy(h->ev_lstm[i]);
-  }
-  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  h->release_streams();
   for (hipEvent_t e : h->ev_sub) hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i)
-    for (int k = 0; k < 4; ++k)
-      if (h->ev_side[i][k]) hipEventDestroy(h->ev_side[i][k]);
   delete h;
 }
 
@@ -1827,6 +1830,10 @@ static size_t grad_scratch_floats(dptnav_handle h) {
   return o;
 }
 static int train_split(dptnav_handle h, int B, int64_t T, int Tv, TrainSplit* sp) {
+  // checked HERE (sizes, forward, backward all come through), not in the last stage of the backward: video_linear_bwd_kernel
+  // keeps one (mixture, feature) column of both speakers' frames in LDS
+  if (!h->cfg.audio_only && Tv > 256)
+    return h->fail(DPTNAV_ERR_INVALID, "training step: at most 256 video frames per mixture (Tv=%d); inference has no such limit", Tv);
   sp->nhalf = (h->opt_overlap && h->opt_train_overlap && B >= 2) ? 2 : 1;
   sp->Bh[0] = sp->nhalf == 2 ? (B + 1) / 2 : B;
   sp->Bh[1] = sp->nhalf == 2 ? B / 2 : 0;

@@ -390,3 +390,21 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     from speech_separation_amd.train import clip_grad_norm_
     norm = clip_grad_norm_(model, 10.0)
     assert abs(float(norm) - float(z["val.grad_norm"])) < 1e-4 * float(z["val.grad_norm"])
+
+
+def test_training_rejects_long_video_before_launching_anything(dev):
+    """the training step's limit of 256 video frames is reported by the size queries / dptnav_train_forward,
+    not by the last stage of the backward after the whole step has run; inference takes the same clip."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import synthetic_inputs
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1, "dropout": 0.0})
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(synthetic_state_dict(cfg, seed=1), dev))
+    eng.bind_grads()
+    inp = synthetic_inputs(cfg, B=2, T=2000, Tv=300, seed=2)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    with pytest.raises(RuntimeError, match="at most 256 video frames"):
+        eng.train_forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
+    s1, s2 = eng.forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
+    torch.cuda.synchronize()
+    assert torch.isfinite(s1).all() and torch.isfinite(s2).all()
