@@ -56,17 +56,21 @@ __global__ __launch_bounds__(256) void lstm_bptt16_kernel(const float* __restric
   const float* whh = d ? whh_b : whh_f;
 
   // B operand of dh_prev = dP W_hh:  B[k = gate column][j = hidden unit] = W_hh[k][32w + 16*half + i16]
+  // (in eight pieces: a piece's 32 loads land in VGPRs and are handed to the AGPRs before the next piece is requested --
+  //  with all 256 in flight at once the prologue needed 269 VGPRs and spilled 13 of them, 56 B/lane of scratch)
   float wf[2][128];
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-    for (int m = 0; m < 32; ++m)
+    for (int q = 0; q < 4; ++q) {        // a quarter of a half: 32 loads in flight, then their hand-over
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wf[hf][4 * m + t] = whh[(int64_t)(16 * m + 4 * ks + t) * LSTM_H + 32 * w + 16 * hf + i16];
+      for (int m = 8 * q; m < 8 * q + 8; ++m)
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
+        for (int t = 0; t < 4; ++t) wf[hf][4 * m + t] = whh[(int64_t)(16 * m + 4 * ks + t) * LSTM_H + 32 * w + 16 * hf + i16];
 #pragma unroll
-    for (int i = 0; i < 128; ++i) asm volatile("" : "+a"(wf[hf][i]));
+      for (int i = 32 * q; i < 32 * q + 32; ++i) asm volatile("" : "+a"(wf[hf][i]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
   const int tstride = seq_token_stride(g);
   // processing order: against the forward order of this direction; the forward-order predecessor of t is the NEXT
