@@ -232,8 +232,13 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 data-gradient GEMMs of those layers (they stage the same dY tile); 0 = separate weight-gradient launches.
  *   "wgrad_side" (0/1, default 1): training with a split batch runs the LSTM weight-gradient launches on a side stream per
  *                 half (two more dP buffers in the backward workspace); 0 = in the half's own stream.
- *   "sub_batches" (0..32, default 0): how many sub-batches dptnav_forward cuts a batch into; 0 = its own rule (as few
- *                 as make every recurrence launch fit the chip in one round, at least two).  A measurement knob
+ *   "split_policy" (0/1, default 1): how dptnav_forward cuts a batch of DPTN blocks.  1 = sub-batches small enough that TWO
+ *                 recurrence launches fit the chip together (6 + 5 + 5 mixtures at B = 16), two of them in flight, when that
+ *                 gives exactly three sub-batches (B = 13..18 at T = 32000); 0 (and everything else) = as few sub-batches as make every recurrence
+ *                 launch fit the chip in one round, at least two, one recurrence in flight.  Set it before
+ *                 dptnav_workspace_bytes.  "lstm_inflight" (0..32, default 0 = the policy's choice) overrides the number of
+ *                 recurrence launches in flight (tools/inflight_sweep.py).
+ *   "sub_batches" (0..32, default 0): how many sub-batches dptnav_forward cuts a batch into; 0 = the policy above.  A measurement knob
  *                 (tools/subbatch_sweep.py): results of different cuts agree to fp32 rounding, not bit for bit.  Set it
  *                 before dptnav_workspace_bytes -- the workspace is sized for the cut.
  *   "split_bf16" (0/1, default 0): OPT-IN experiment, never a parity claim -- the 16-sequence-tile recurrence of the

@@ -12,6 +12,7 @@
 #include "../../include/dptnav.h"
 #include "attention.h"
 #include "attn_block.h"
+#include "attn_block64.h"
 #include "common.h"
 #include "gemm_ws.h"
 #include "headtail.h"
@@ -104,6 +105,8 @@ struct dptnav_ctx {
   hipEvent_t ev_side[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // side streams of the training backward
   bool opt_wgrad_side = true;       // training, split batches: LSTM weight gradients on a side stream per half
   int opt_sub_batches = 0;          // 0: forward_split decides; n > 0: that many sub-batches (experiments)
+  int opt_lstm_inflight = 0;        // > 0: that many recurrence launches of dptnav_forward's sub-batches in flight (experiments)
+  int opt_split_policy = 1;         // 1: sub-batch pairs with two recurrences in flight where >= 3 sub-batches result; 0: round-2 rule
   std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
   int ensure_sub_events(int n) {
     while ((int)ev_sub.size() < n) {
@@ -478,7 +481,9 @@ constexpr int CHAIN_PRO = 1, CHAIN_SKIP_FFN = 2;
 template <int N>
 bool path_fusable(const dptnav_ctx* c, int path, int B, int S) {
   const SeqGeom geom = make_geom(path, B, S, c->cfg.chunk_size);
-  return c->cfg.arch == 0 && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && c->cfg.num_heads == 4;
+  // N = 128: attn_block.hip (fp32 and split variants); N = 64: attn_block64.hip (fp32 only)
+  return c->cfg.arch == 0 && (N == 128 || (N == 64 && !c->opt_split_bf16)) && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN &&
+         c->cfg.num_heads == 4;
 }
 
 // fragment-order copies of the attention / FFN weights of paths [first, first + n) for the fused attention block, from
@@ -515,8 +520,20 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
 
   // K1 + K2 + K3 in one launch (inference, N = 128, sequences of <= 160 positions): QKV and the attention output never
   // leave the chip -- 1 kB of HBM traffic per token instead of 5.5 kB
-  const bool fused = dptn && !pb.train && N == 128 && c->opt_fuse_attn && geom.len <= ATTN_BLOCK_MAX_LEN && g.num_heads == 4;
-  if (fused) {
+  const bool fused = dptn && !pb.train && path_fusable<N>(c, path, B, S);
+  if (fused && (chain & CHAIN_PRO) && c->pw[2 * block + path - 1].ndir != 2)
+    return c->fail(DPTNAV_ERR_INVALID, "internal: FFN prologue needs both LSTM directions of the previous path");
+  if (fused && N == 64) {
+    ProfScope ps(c, CAT_ATTN, st);
+    AttnFfnPrologue pro{};
+    if (chain & CHAIN_PRO) {
+      const PathWeights& pw = c->pw[2 * block + path - 1];
+      pro = AttnFfnPrologue{hc, pw.ffn_w, pw.ffn_b, pw.ln2_w, pw.ln2_b};
+    }
+    const int rc = attn_block64_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom,
+                                       (chain & CHAIN_PRO) ? &pro : nullptr);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention block (N = 64): %s", hipGetErrorString((hipError_t)rc));
+  } else if (fused) {
     ProfScope ps(c, CAT_ATTN, st);
     AttnFfnPrologue pro{};
     if (chain & CHAIN_PRO) {
@@ -1437,22 +1454,41 @@ int64_t dptnav_chunks(dptnav_handle h, int64_t T) {
 // round 1) so that one sub-batch's recurrence always has another one's GEMM / attention kernels beside it.  Sequences
 // too long for that (fewer than 4 mixtures would fit) keep the plain two halves.
 constexpr int MAX_SUB = 32;
-static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes) {
+// -> number of sub-batches; *inflight (optional) = how many of their recurrence launches may run side by side.
+// Policy "pairs" (option split_policy = 1, the default): a recurrence launch takes its 150 / 141 steps whatever its
+// batch and occupies one CU per (direction, 16-sequence tile), so the chain of launches is the critical path once the
+// other kernels are short (N = 64: 19.2 of 20.1 ms).  Sub-batches small enough that TWO launches fit the chip together
+// (6 + 5 + 5 mixtures at B = 16: 106 + 94 workgroups) with two of them in flight shorten that chain by a third while the
+// third sub-batch's GEMM / attention kernels keep the remaining CUs busy: 20.1 -> 19.2 ms (N = 64), 31.3 -> 30.9 ms
+// (N = 128).  Applied when it yields exactly three sub-batches (B = 13..18); otherwise, and with split_policy = 0, the
+// round-2 rule applies.
+static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes, int* inflight = nullptr) {
+  if (inflight) *inflight = 1;
   if (!h->opt_overlap || B < 2) { sizes[0] = B; return 1; }
   Plan pl;
-  int nsub = 2;
+  int nsub = 2, depth = 1;
   if (h->opt_lstm16 && make_plan(h, 1, T, Tv, &pl) == DPTNAV_OK) {
     const int64_t S = pl.S, K = h->cfg.chunk_size;
     const int ndir_inter = h->cfg.bidir ? 2 : 1;
-    auto fits = [&](int b) { return ((b * S + 15) / 16) * 2 <= h->num_cus && ((b * K + 15) / 16) * ndir_inter <= h->num_cus; };
+    auto wgs = [&](int b) { return std::max(((b * S + 15) / 16) * 2, ((b * K + 15) / 16) * ndir_inter); };
     int bfit = 0;
-    while (bfit < B && fits(bfit + 1)) ++bfit;
+    while (bfit < B && wgs(bfit + 1) <= h->num_cus) ++bfit;
     if (bfit >= 4) nsub = std::max(2, (B + bfit - 1) / bfit);
+    if (h->opt_split_policy == 1 && h->cfg.arch == 0) {
+      int bpair = 0;
+      while (bpair < B && 2 * wgs(bpair + 1) <= h->num_cus) ++bpair;
+      const int n2 = bpair >= 2 ? (B + bpair - 1) / bpair : 0;
+      // exactly three: measured (tools/inflight_sweep.py policy) +5.1 % / +1.3 % at B = 16 (N = 64 / 128), but -5..-12 % for
+      // B >= 24, where four or more small sub-batches lose to two large ones (12 + 12 mixtures: 226 workgroups per launch)
+      if (n2 == 3) { nsub = n2; depth = 2; }
+    }
   }
-  if (h->opt_sub_batches > 0) nsub = h->opt_sub_batches;
+  if (h->opt_sub_batches > 0) { nsub = h->opt_sub_batches; depth = 1; }
+  if (h->opt_lstm_inflight > 0) depth = h->opt_lstm_inflight;
   if (nsub > MAX_SUB) nsub = MAX_SUB;
   if (nsub > B) nsub = B;
   for (int i = 0; i < nsub; ++i) sizes[i] = B / nsub + (i < B % nsub ? 1 : 0);
+  if (inflight) *inflight = std::max(1, std::min(depth, nsub));
   return nsub;
 }
 
@@ -1540,7 +1576,8 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   // recurrence launch occupies one CU per (direction, 16-sequence tile), and the other stream's GEMM / attention
   // launches (dynamic tile tickets) fill the rest of the chip meanwhile.  Fork/join by events on the caller's stream.
   int Bs[MAX_SUB];
-  const int nsub = forward_split(h, B, T, Tv, Bs);
+  int depth = 1;
+  const int nsub = forward_split(h, B, T, Tv, Bs, &depth);
   Plan pl[MAX_SUB];
   size_t need = 0, base[MAX_SUB];
   for (int i = 0; i < nsub; ++i) {
@@ -1594,12 +1631,14 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
       run[i].packed = true;
     }
   }
-  int prev = -1;
+  // recurrence launch n (path-major, sub-batch minor) waits for launch n - depth: `depth` recurrences may be in flight
+  // (forward_split; > 1 pays when two launches fit the chip together: three or more sub-batches).  ev_sub[j] is re-recorded by sub-batch j once per path, so its latest record IS launch n - depth.
+  int nlaunch = 0;
   for (int b = 0; b < g.num_blocks; ++b)
     for (int path = 0; path < 2; ++path)
-      for (int i = 0; i < nsub; ++i) {
+      for (int i = 0; i < nsub; ++i, ++nlaunch) {
         if (nsub > 1) {
-          run[i].lstm_wait = prev >= 0 ? h->ev_sub[prev] : nullptr;
+          run[i].lstm_wait = nlaunch >= depth && depth < nsub ? h->ev_sub[(nlaunch - depth) % nsub] : nullptr;
           run[i].lstm_record = h->ev_sub[i];
         }
         const float* xin = path == 0 ? X0(i) : X1(i);
@@ -1607,16 +1646,20 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
         // FFN (K6) of a path runs as the prologue of the NEXT path's attention block when that block is the fused kernel
         // (fp32, N = 128, sequences <= 160): the block input x then never goes through HBM
         int chain = 0;
-        if (big && h->opt_fuse_ffn && !h->opt_split_bf16) {
+        if (h->opt_fuse_ffn && !h->opt_split_bf16) {
           const int S_i = (int)pl[i].S;
           const bool first = b == 0 && path == 0, last = b == g.num_blocks - 1 && path == 1;
-          if (!first && path_fusable<128>(h, path, Bs[i], S_i)) chain |= CHAIN_PRO;
-          if (!last && path_fusable<128>(h, 1 - path, Bs[i], S_i)) chain |= CHAIN_SKIP_FFN;
+          auto fusable = [&](int p) { return big ? path_fusable<128>(h, p, Bs[i], S_i) : path_fusable<64>(h, p, Bs[i], S_i); };
+          // the prologue contracts over ReLU(h) of BOTH directions (K = 256): a unidirectional inter-chunk LSTM
+          // (bidir = false) keeps its own K6 launch
+          const bool this_two = h->pw[2 * b + path].ndir == 2;
+          const bool prev_two = first || h->pw[2 * b + path - 1].ndir == 2;
+          if (!first && prev_two && fusable(path)) chain |= CHAIN_PRO;
+          if (!last && this_two && fusable(1 - path)) chain |= CHAIN_SKIP_FFN;
         }
         int rc = big ? run_path<128>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S, nullptr, chain)
-                     : run_path<64>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S);
+                     : run_path<64>(h, run[i], b, path, xin, xout, Bs[i], (int)pl[i].S, nullptr, chain);
         if (rc) return rc;
-        prev = i;
       }
   for (int i = 0; i < nsub; ++i) {
     int rc = big ? run_tail<128>(h, run[i], X0(i), E(i), Bs[i], T, s1i[i], s2i[i])
@@ -2076,6 +2119,8 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "wgrad_ride") h->opt_wgrad_ride = value != 0;
   else if (k == "wgrad_side") h->opt_wgrad_side = value != 0;
   else if (k == "sub_batches" && value >= 0 && value <= MAX_SUB) h->opt_sub_batches = value;
+  else if (k == "lstm_inflight" && value >= 0 && value <= MAX_SUB) h->opt_lstm_inflight = value;
+  else if (k == "split_policy" && (value == 0 || value == 1)) h->opt_split_policy = value;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
