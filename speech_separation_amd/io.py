@@ -53,23 +53,53 @@ def collate(items: Sequence[Mapping[str, object]]) -> Dict[str, object]:
     return batch
 
 
+def resample(wave: torch.Tensor, orig_sr: int, new_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """Band-limited sample-rate conversion of (..., T) float32 waveforms on the CPU: a restatement of what the reference's
+    ``torchaudio.functional.resample(audio, sr, target_sr)`` (base_dataset.py:142-148) computes with its defaults --
+    windowed-sinc interpolation (Hann window, 6 zero crossings, cut-off at 0.99 of the lower Nyquist) applied as one strided
+    convolution with `new_sr / gcd` polyphase kernels; output length ceil(T * new_sr / orig_sr).
+    torchaudio is a third-party dependency that is not installed here and the reference holds no fixture for it: PARITY
+    UNPINNED (properties only: tests/test_io.py)."""
+    import math
+    if orig_sr <= 0 or new_sr <= 0:
+        raise ValueError("sample rates must be positive")
+    if orig_sr == new_sr:
+        return wave
+    g = math.gcd(int(orig_sr), int(new_sr))
+    orig, new = int(orig_sr) // g, int(new_sr) // g
+    base = min(orig, new) * rolloff
+    width = int(math.ceil(lowpass_filter_width * orig / base))
+    idx = torch.arange(-width, width + orig, dtype=torch.float64) / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx[None, :]
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)      # (new, 2 width + orig)
+    shape, T = wave.shape[:-1], wave.shape[-1]
+    x = torch.nn.functional.pad(wave.reshape(-1, 1, T).to(torch.float32), (width, width + orig))
+    y = torch.nn.functional.conv1d(x, kernels.to(torch.float32)[:, None, :], stride=orig)           # (n, new, frames)
+    y = y.transpose(1, 2).reshape(y.shape[0], -1)[:, :int(math.ceil(new * T / orig))]
+    return y.reshape(*shape, y.shape[-1])
+
+
 def load_audio(path: str, target_sr: Optional[int] = None) -> torch.Tensor:
     """(1, T) float32 in [-1, 1): first channel of a PCM WAV file, as BaseDataset.load_audio returns it
-    (base_dataset.py:137-145; torchaudio.load normalises integer PCM by 2^(bits-1)).  Resampling is not built: a file
-    whose rate differs from `target_sr` raises instead of being passed through."""
+    (base_dataset.py:137-148; torchaudio.load normalises integer PCM by 2^(bits-1)), converted to `target_sr` when the
+    file's rate differs (`resample`)."""
     import wave
     with wave.open(path, "rb") as w:
         sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
         raw = w.readframes(n)
-    if target_sr is not None and sr != target_sr:
-        raise ValueError(f"{path}: sample rate {sr} != {target_sr} (resampling is outside this path)")
     if width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif width == 4:
         x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
     else:
         raise ValueError(f"{path}: unsupported PCM sample width {width}")
-    return torch.from_numpy(np.ascontiguousarray(x.reshape(-1, nch)[:, 0])).unsqueeze(0)
+    audio = torch.from_numpy(np.ascontiguousarray(x.reshape(-1, nch)[:, 0])).unsqueeze(0)
+    if target_sr is not None and sr != target_sr:
+        audio = resample(audio, sr, target_sr)
+    return audio
 
 
 def load_item(entry: Mapping[str, Optional[str]], target_sr: Optional[int] = None) -> Dict[str, object]:

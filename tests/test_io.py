@@ -62,8 +62,8 @@ def test_wav_and_item_loading(tmp_path):
     entries, truth = make_dataset(str(tmp_path), n=2, T=801, Tv=7, emb=16)
     a = load_audio(entries[1]["mix_wav_path"], target_sr=8000)
     assert a.shape == (1, 801) and a.dtype == torch.float32 and np.array_equal(a[0].numpy(), truth[1]["mix"])
-    with pytest.raises(ValueError, match="sample rate"):
-        load_audio(entries[1]["mix_wav_path"], target_sr=16000)
+    up = load_audio(entries[1]["mix_wav_path"], target_sr=16000)      # a rate mismatch is resampled (base_dataset.py:146-147)
+    assert up.shape == (1, 1602) and up.dtype == torch.float32 and torch.isfinite(up).all()
     it = load_item(entries[0], target_sr=8000)
     assert it["audio_path"] == entries[0]["mix_wav_path"] and it["s1_video"] is None
     assert it["s1_embedding"].shape == (1, 16, 7) and np.array_equal(it["s2_embedding"][0].numpy(), truth[0]["s2_embedding"])
@@ -72,3 +72,33 @@ def test_wav_and_item_loading(tmp_path):
     assert no_gt["s1"] is None and no_gt["s1_embedding"] is None
     b = collate([load_item(e) for e in entries])
     assert b["mix"].shape == (2, 801) and b["s1_video"] is None
+
+
+def test_resample_properties():
+    """io.resample restates torchaudio.functional.resample's defaults (third-party, not installed: parity unpinned), so it is
+    checked through what a band-limited rate conversion must do: length ceil(T new / orig), identity for equal rates, a
+    tone well inside both bands keeps frequency, amplitude and phase (away from the edges), a tone above the new Nyquist is
+    removed, batch rows are independent, and down- then up-sampling a band-limited signal gives it back."""
+    import math
+    from speech_separation_amd.io import resample
+    sr = 16000
+    t = torch.arange(16000, dtype=torch.float64) / sr
+    tone = torch.sin(2 * math.pi * 440.0 * t).float()[None]
+    assert resample(tone, sr, sr) is tone
+    for new in (8000, 22050, 48000, 11025):
+        y = resample(tone, sr, new)
+        n = int(math.ceil(16000 * new / sr))
+        assert y.shape == (1, n)
+        tn = torch.arange(n, dtype=torch.float64) / new
+        want = torch.sin(2 * math.pi * 440.0 * tn).float()
+        core = slice(200, n - 200)
+        err = (y[0, core] - want[core]).pow(2).mean().sqrt()
+        assert float(err) < 5e-3, (new, float(err))
+    # 6 kHz is above the 4 kHz Nyquist of 8 kHz: filtered out (stop band of a 6-zero-crossing Hann-windowed sinc: < -30 dB)
+    high = torch.sin(2 * math.pi * 6000.0 * t).float()[None]
+    assert float(resample(high, sr, 8000)[0, 200:-200].abs().max()) < 0.05
+    both = torch.cat([tone, high])
+    yb = resample(both, sr, 8000)
+    assert torch.allclose(yb[0:1], resample(tone, sr, 8000), atol=1e-6) and torch.allclose(yb[1:2], resample(high, sr, 8000), atol=1e-6)
+    back = resample(resample(tone, sr, 8000), 8000, sr)
+    assert back.shape == tone.shape and float((back - tone)[0, 400:-400].abs().max()) < 1e-2
