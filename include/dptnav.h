@@ -230,6 +230,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 (direction, gate-row half) problems of a path in one launch; 0 = eight single-gradient launches.
  *   "wgrad_ride" (0/1, default 1): training forms the out-projection and ffn.1 weight / bias gradients inside the
  *                 data-gradient GEMMs of those layers (they stage the same dY tile); 0 = separate weight-gradient launches.
+ *   "ln_tape" (0/1, default 1): the training forward leaves the normalised rows and 1/sigma of both LayerNorms of a path on the
+ *                 tape (1 kB per token and path more) and the backward applies the LayerNorm derivative in a bandwidth-bound
+ *                 pass; 0 = recompute the pre-LayerNorm rows in a GEMM with a derivative epilogue (round 2).  Set it before
+ *                 dptnav_train_tape_bytes: the tape is sized for it.
  *   "wgrad_side" (0/1, default 1): training with a split batch runs the LSTM weight-gradient launches on a side stream per
  *                 half (two more dP buffers in the backward workspace); 0 = in the half's own stream.
  *   "split_policy" (0/1, default 1): how dptnav_forward cuts a batch of DPTN blocks.  1 = sub-batches small enough that TWO

@@ -440,6 +440,68 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// LayerNorm backward from the rows the training forward left on the tape (EpiBiasResLNSave: zn = (z - mu) rstd, rstd):
+//   dz = rstd * (g - mean(g) - zn * mean(g * zn)),  g = dout * gamma;   d gamma += dout * zn,  d beta += dout
+// (dptn.py:47,51).  Bandwidth-bound: 1.5 kB per token for N = 128; a row = N/4 adjacent lanes, four rows in flight per
+// thread.  Column sums per thread -> per workgroup through LDS -> partials[gridDim.x][2 N] (d gamma | d beta), reduced in
+// a fixed order by slab_reduce_to2_kernel, like the partials of EpiLNBackward.
+template <int N>
+__global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restrict__ dout, const float* __restrict__ zn,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           float* __restrict__ dz, float* __restrict__ partials, int64_t M) {
+  constexpr int GROUP = N / 4, RPB = 256 / GROUP, U = 4;
+  __shared__ float4 red[2][256];
+  const int tid = threadIdx.x, rl = tid / GROUP, c4 = tid % GROUP;
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+  const int64_t npass = (M + RPB - 1) / RPB;
+  for (int64_t p0 = blockIdx.x; p0 < npass; p0 += (int64_t)U * gridDim.x) {
+    float4 d[U], z[U];
+    float rs[U];
+    bool ok[U];
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = (p0 + (int64_t)u * gridDim.x) * RPB + rl;
+      ok[u] = r < M;
+      row[u] = ok[u] ? r : M - 1;
+      d[u] = mask4(*reinterpret_cast<const float4*>(dout + row[u] * N + 4 * c4), ok[u]);
+      z[u] = *reinterpret_cast<const float4*>(zn + row[u] * N + 4 * c4);
+      rs[u] = rstd[row[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sg.x += d[u].x * z[u].x; sg.y += d[u].y * z[u].y; sg.z += d[u].z * z[u].z; sg.w += d[u].w * z[u].w;
+      sb.x += d[u].x; sb.y += d[u].y; sb.z += d[u].z; sb.w += d[u].w;
+      const float4 g = make_float4(d[u].x * ga.x, d[u].y * ga.y, d[u].z * ga.z, d[u].w * ga.w);
+      const float m1 = group_sum<GROUP>((g.x + g.y) + (g.z + g.w)) * (1.0f / N);
+      const float m2 = group_sum<GROUP>((g.x * z[u].x + g.y * z[u].y) + (g.z * z[u].z + g.w * z[u].w)) * (1.0f / N);
+      if (ok[u]) {
+        float4 o;
+        o.x = rs[u] * (g.x - m1 - z[u].x * m2);
+        o.y = rs[u] * (g.y - m1 - z[u].y * m2);
+        o.z = rs[u] * (g.z - m1 - z[u].z * m2);
+        o.w = rs[u] * (g.w - m1 - z[u].w * m2);
+        *reinterpret_cast<float4*>(dz + row[u] * N + 4 * c4) = o;
+      }
+    }
+  }
+  red[0][tid] = sg;
+  red[1][tid] = sb;
+  __syncthreads();
+  if (tid < GROUP) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int k = tid; k < 256; k += GROUP) {
+      const float4 u = red[0][k], w = red[1][k];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+    }
+    float* pp = partials + (size_t)blockIdx.x * (2 * N);
+    *reinterpret_cast<float4*>(pp + 4 * tid) = a;
+    *reinterpret_cast<float4*>(pp + N + 4 * tid) = b;
+  }
+}
+
 // slab_reduce_kernel with two destinations (overwrite): split >= 0: elements [0, split) go to out_a, the rest to out_b
 // (LayerNorm: d gamma | d beta from one slab row); split < 0: every element goes to both (b_ih and b_hh have the same
 // gradient).  Same association order as slab_reduce_kernel.

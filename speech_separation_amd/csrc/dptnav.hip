@@ -84,6 +84,7 @@ struct dptnav_ctx {
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
   bool opt_wgrad_ride = true;       // training: out-projection / ffn weight gradients formed inside their data-gradient GEMMs
   bool opt_wgrad2 = true;           // training: LSTM W_ih / W_hh gradients in one pass over dP (wgrad2_kernel)
+  bool opt_ln_tape = true;          // training: LayerNorm backward from zn / rstd left on the tape instead of a recomputed GEMM
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
@@ -458,6 +459,8 @@ struct PathBufs {
   float *qkv, *att, *y1, *pre, *hc, *gates, *cst;
   bool train;
   float* astats = nullptr;   // training: where the attention forward leaves its softmax statistics
+  // training, option ln_tape: normalised rows and 1/sigma of LayerNorm 1 / LayerNorm 2 for the backward (EpiBiasResLNSave)
+  float *zn1 = nullptr, *rs1 = nullptr, *zn2 = nullptr, *rs2 = nullptr;
 };
 inline PathBufs inference_bufs(const Run& run) {
   return PathBufs{run.ws + run.pl.qkv, run.ws + run.pl.att, run.ws + run.pl.y1, run.ws + run.pl.pre,
@@ -569,8 +572,18 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
   if (dptn && !fused) {
     ALoadDense al{att, M, N, BM};
-    EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
-    if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
+    bool done = false;
+    if constexpr (N == 128) {
+      if (pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
+        EpiBiasResLNSave<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM, pb.zn1, pb.rs1};
+        if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm (tape)", w.out_w, ntiles, 1, al, ep)) return rc;
+        done = true;
+      }
+    }
+    if (!done) {
+      EpiBiasResLN<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM};
+      if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm", w.out_w, ntiles, 1, al, ep)) return rc;
+    }
   }
   const int nst16 = (geom.nseq + 15) / 16;
   const bool use16 = lstm_use16(c, geom, w.ndir, M);
@@ -653,7 +666,16 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC, false, true>(c, run, CAT_FFN, "ffn gemm (split)", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else if (w.ndir == 2 && pb.train) {
       ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, BM};
-      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+      bool done = false;
+      if constexpr (N == 128) {
+        if (pb.zn2) {
+          EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
+          if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
+          done = true;
+        }
+      }
+      if (!done)
+        if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else if (w.ndir == 2) {
       ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -753,6 +775,7 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
 // =================================================================================================
 struct PathTape {  // offsets in floats inside one path's tape
   size_t qkv, att, y1, hc, gates, cst, astats, total;   // astats: softmax (max, 1/sum) per (token, head)
+  size_t zn1, rs1, zn2, rs2;   // option ln_tape: LayerNorm 1 / 2 normalised rows [M][N] and 1/sigma [M]; 0 when off
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
@@ -775,6 +798,13 @@ int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
   t->gates = take((size_t)2 * nst * 512 * 32);
   t->cst = take((size_t)2 * nst * 128 * 32);
   t->astats = take((size_t)M * g.num_heads * 2);
+  t->zn1 = t->rs1 = t->zn2 = t->rs2 = 0;
+  if (c->opt_ln_tape) {
+    t->zn1 = take((size_t)M * N);
+    t->rs1 = take((size_t)M);
+    t->zn2 = take((size_t)M * N);
+    t->rs2 = take((size_t)M);
+  }
   t->total = o;
   return DPTNAV_OK;
 }
@@ -965,8 +995,19 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   int grid = 0;
 
-  // 1. recompute z2 = relu(h) W_f^T + b_f + y1 and push d_out through LayerNorm 2
-  {
+  // 1. push d_out through LayerNorm 2: from the tape's zn / rstd (option ln_tape), or by recomputing
+  //    z2 = relu(h) W_f^T + b_f + y1 in a GEMM whose epilogue applies the derivative
+  auto ln_from_tape = [&](const float* dout, const float* zn, const float* rs, const float* gamma, const char* gw, const char* gb) {
+    const int64_t npass = (M + 7) / 8;
+    const int lgrid = (int)std::min<int64_t>(std::min<int64_t>(BWD_LNP_WGS, 4 * (int64_t)c->num_cus), (npass + 3) / 4);
+    ProfScope ps(c, CAT_FFN, st);
+    hipLaunchKernelGGL(ln_backward_kernel<N>, dim3(lgrid), dim3(256), 0, st, dout, zn, rs, gamma, DZ, LNP, M);
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, lgrid, (int64_t)2 * N, G(gw), G(gb), N);
+    return hipGetLastError() == hipSuccess;
+  };
+  if (tp.zn2) {
+    if (!ln_from_tape(d_out, tape + tp.zn2, tape + tp.rs2, w.ln2_w, "ln2.weight", "ln2.bias")) return c->fail(DPTNAV_ERR_HIP, "ln2 backward");
+  } else {
     ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, 32};
     EpiLNBackward<GROUP, 0> ep{DZ, w.ffn_b, y1, w.ln2_w, d_out, LNP, M, N, 32};
     if (int rc = launch_gemm<2 * LSTM_H, 1, 1, 4>(c, run, CAT_FFN, "ffn recompute + ln2 bwd", w.ffn_w, ntiles, 1, al, ep,
@@ -1082,8 +1123,10 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
       return rc;
   }
-  // 7. recompute z1 = att W_o^T + b_o + x and push d y1 through LayerNorm 1
-  {
+  // 7. push d y1 through LayerNorm 1 (tape, or recompute z1 = att W_o^T + b_o + x)
+  if (tp.zn1) {
+    if (!ln_from_tape(DY1, tape + tp.zn1, tape + tp.rs1, w.ln1_w, "ln1.weight", "ln1.bias")) return c->fail(DPTNAV_ERR_HIP, "ln1 backward");
+  } else {
     ALoadDense al{att, M, N, 32};
     EpiLNBackward<GROUP, 0> ep{DZ, w.out_b, x_in, w.ln1_w, DY1, LNP, M, N, 32};
     if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_OUTPROJ, "out-proj recompute + ln1 bwd", w.out_w, ntiles, 1, al, ep,
@@ -1819,6 +1862,7 @@ int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float*
   if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
   float* tb = (float*)tape;
   PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true, tb + tp.astats};
+  if (tp.zn1) { pb.zn1 = tb + tp.zn1; pb.rs1 = tb + tp.rs1; pb.zn2 = tb + tp.zn2; pb.rs2 = tb + tp.rs2; }
   return run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb);
 }
 int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
@@ -1958,6 +2002,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
       PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run[i].ws + sp.pl[i].pre, pt + mt.pt.hc, pt + mt.pt.gates,
                   pt + mt.pt.cst, true, pt + mt.pt.astats};
+      if (mt.pt.zn1) { pb.zn1 = pt + mt.pt.zn1; pb.rs1 = pt + mt.pt.rs1; pb.zn2 = pt + mt.pt.zn2; pb.rs2 = pt + mt.pt.rs2; }
       if (int rc = run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
                                  tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb))
         return rc;
@@ -2115,6 +2160,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
+  else if (k == "ln_tape") h->opt_ln_tape = value != 0;
   else if (k == "fold_tail") h->opt_fold_tail = value != 0;
   else if (k == "wgrad_ride") h->opt_wgrad_ride = value != 0;
   else if (k == "wgrad_side") h->opt_wgrad_side = value != 0;
