@@ -69,7 +69,7 @@ def host_cores() -> int:
 
 
 PMC_TABLE = os.path.join(ROOT, "profiles", "r03_b_pmc_traffic.json")
-PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r02_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
+PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r03_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
 
 
 def pmc_table(config: str, path: str = None):
