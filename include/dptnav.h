@@ -236,12 +236,13 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 dptnav_train_tape_bytes: the tape is sized for it.
  *   "wgrad_side" (0/1, default 1): training with a split batch runs the LSTM weight-gradient launches on a side stream per
  *                 half (two more dP buffers in the backward workspace); 0 = in the half's own stream.
- *   "split_policy" (0/1, default 1): how dptnav_forward cuts a batch of DPTN blocks.  1 = sub-batches small enough that TWO
- *                 recurrence launches fit the chip together (6 + 5 + 5 mixtures at B = 16), two of them in flight, when that
- *                 gives exactly three sub-batches (B = 13..18 at T = 32000); 0 (and everything else) = as few sub-batches as make every recurrence
- *                 launch fit the chip in one round, at least two, one recurrence in flight.  Set it before
- *                 dptnav_workspace_bytes.  "lstm_inflight" (0..32, default 0 = the policy's choice) overrides the number of
- *                 recurrence launches in flight (tools/inflight_sweep.py).
+ *   "split_policy" (0/1, default 1): 1 = three sub-batches where a half-batch recurrence launch needs more than half of the
+ *                 CUs but a third needs less (B = 13..18 at T = 32000); 0 = always as few sub-batches as make every
+ *                 recurrence launch fit the chip in one round, at least two.  Set it before dptnav_workspace_bytes.
+ *   "lstm_chain" (0/1, default 0): 1 = the recurrence (and BPTT) launches of the sub-batches / halves are chained by events so
+ *                 that one is in flight at a time (the schedule of rounds 1-2; measured slower at every batch size in round
+ *                 3); "lstm_inflight" (0..32, default 0 = off) sets the depth of that chain for experiments
+ *                 (tools/split_sweep.py).
  *   "sub_batches" (0..32, default 0): how many sub-batches dptnav_forward cuts a batch into; 0 = the policy above.  A measurement knob
  *                 (tools/subbatch_sweep.py): results of different cuts agree to fp32 rounding, not bit for bit.  Set it
  *                 before dptnav_workspace_bytes -- the workspace is sized for the cut.

@@ -108,6 +108,7 @@ struct dptnav_ctx {
   int opt_sub_batches = 0;          // 0: forward_split decides; n > 0: that many sub-batches (experiments)
   int opt_lstm_inflight = 0;        // > 0: that many recurrence launches of dptnav_forward's sub-batches in flight (experiments)
   int opt_split_policy = 1;         // 1: sub-batch pairs with two recurrences in flight where >= 3 sub-batches result; 0: round-2 rule
+  bool opt_lstm_chain = false;      // 1: at most one recurrence / BPTT launch of the sub-batches in flight (event chain, rounds 1-2)
   std::vector<hipEvent_t> ev_sub;   // recurrence-chain events of dptnav_forward's sub-batches (created on demand)
   int ensure_sub_events(int n) {
     while ((int)ev_sub.size() < n) {
@@ -1497,14 +1498,16 @@ int64_t dptnav_chunks(dptnav_handle h, int64_t T) {
 // round 1) so that one sub-batch's recurrence always has another one's GEMM / attention kernels beside it.  Sequences
 // too long for that (fewer than 4 mixtures would fit) keep the plain two halves.
 constexpr int MAX_SUB = 32;
-// -> number of sub-batches; *inflight (optional) = how many of their recurrence launches may run side by side.
-// Policy "pairs" (option split_policy = 1, the default): a recurrence launch takes its 150 / 141 steps whatever its
-// batch and occupies one CU per (direction, 16-sequence tile), so the chain of launches is the critical path once the
-// other kernels are short (N = 64: 19.2 of 20.1 ms).  Sub-batches small enough that TWO launches fit the chip together
-// (6 + 5 + 5 mixtures at B = 16: 106 + 94 workgroups) with two of them in flight shorten that chain by a third while the
-// third sub-batch's GEMM / attention kernels keep the remaining CUs busy: 20.1 -> 19.2 ms (N = 64), 31.3 -> 30.9 ms
-// (N = 128).  Applied when it yields exactly three sub-batches (B = 13..18); otherwise, and with split_policy = 0, the
-// round-2 rule applies.
+// -> number of sub-batches; *inflight (optional) = how many of their recurrence launches may be in flight together.
+// Round 3 measurements (tools/split_sweep.py -> profiles/r03_split_sweep.txt; B x sub-batches x launches in flight):
+//  * the event chain of rounds 1-2 (ONE recurrence in flight: it had paid with the static-grid GEMMs of round 1) now
+//    costs time at every batch size -- nothing at B >= 20, 1-5 % at B = 12..16, 29 % (N = 128) / 39 % (N = 64) at B = 4,
+//    where both sub-batches' recurrences fit the chip side by side and the chain serialised them.  Default: no chain
+//    (option lstm_chain = 1 restores it; lstm_inflight = n sets the depth for experiments);
+//  * sub-batches: as few as make every recurrence launch fit the 16-sequence-tile kernel in one round, at least two
+//    (8 + 8 at B = 16, 12 + 12 at B = 24, 11 + 11 + 10 at B = 32).  One exception, option split_policy = 1 (default): when
+//    a half-batch launch needs more than half of the CUs but a third needs less (B = 13..18: 6 + 5 + 5 mixtures = 106 +
+//    94 + 94 workgroups) three sub-batches are 1 % faster for N = 128 (30.6 vs 31.0 ms at B = 16) and equal for N = 64.
 static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes, int* inflight = nullptr) {
   if (inflight) *inflight = 1;
   if (!h->opt_overlap || B < 2) { sizes[0] = B; return 1; }
@@ -1521,12 +1524,12 @@ static int forward_split(dptnav_handle h, int B, int64_t T, int Tv, int* sizes, 
       int bpair = 0;
       while (bpair < B && 2 * wgs(bpair + 1) <= h->num_cus) ++bpair;
       const int n2 = bpair >= 2 ? (B + bpair - 1) / bpair : 0;
-      // exactly three: measured (tools/inflight_sweep.py policy) +5.1 % / +1.3 % at B = 16 (N = 64 / 128), but -5..-12 % for
-      // B >= 24, where four or more small sub-batches lose to two large ones (12 + 12 mixtures: 226 workgroups per launch)
-      if (n2 == 3) { nsub = n2; depth = 2; }
+      // exactly three: four or more small sub-batches lose to two large ones (B = 24: 12 + 12 mixtures, 226 workgroups per launch)
+      if (n2 == 3) { nsub = n2; depth = 2; }       // depth: only with the chain (lstm_chain = 1)
     }
   }
   if (h->opt_sub_batches > 0) { nsub = h->opt_sub_batches; depth = 1; }
+  if (!h->opt_lstm_chain) depth = MAX_SUB;       // no chain: every sub-batch's recurrence may be in flight
   if (h->opt_lstm_inflight > 0) depth = h->opt_lstm_inflight;
   if (nsub > MAX_SUB) nsub = MAX_SUB;
   if (nsub > B) nsub = B;
@@ -1996,7 +1999,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
     for (int i = 0; i < sp.nhalf; ++i) {
       const ModelTape& mt = sp.mt[i];
       if (sp.nhalf == 2) {
-        run[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
+        run[i].lstm_wait = have_prev && h->opt_lstm_chain ? h->ev_lstm[1 - i] : nullptr;
         run[i].lstm_record = h->ev_lstm[i];
       }
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
@@ -2102,7 +2105,7 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
         br[i].slot = 0;
       }
       if (sp.nhalf == 2) {
-        br[i].lstm_wait = have_prev ? h->ev_lstm[1 - i] : nullptr;
+        br[i].lstm_wait = have_prev && h->opt_lstm_chain ? h->ev_lstm[1 - i] : nullptr;
         br[i].lstm_record = h->ev_lstm[i];
       }
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
@@ -2167,6 +2170,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "sub_batches" && value >= 0 && value <= MAX_SUB) h->opt_sub_batches = value;
   else if (k == "lstm_inflight" && value >= 0 && value <= MAX_SUB) h->opt_lstm_inflight = value;
   else if (k == "split_policy" && (value == 0 || value == 1)) h->opt_split_policy = value;
+  else if (k == "lstm_chain") h->opt_lstm_chain = value != 0;
   else if (k == "split_bf16") h->opt_split_bf16 = value != 0;
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
