@@ -283,7 +283,7 @@ def test_weight_gradient_schedules_agree(dev):
     results = {}
     for name, opts in {"default": {}, "plain": {"wgrad_ride": 0, "wgrad_side": 0, "wgrad2": 0, "ln_tape": 0},
                        "no side stream": {"wgrad_side": 0}, "no riders": {"wgrad_ride": 0},
-                       "ln recompute": {"ln_tape": 0}}.items():
+                       "ln recompute": {"ln_tape": 0}, "chained recurrences": {"lstm_chain": 1}}.items():
         eng = DptnEngine(cfg, dev)
         eng.bind(params_to_device(sd, dev))
         grads = eng.bind_grads()
@@ -297,7 +297,7 @@ def test_weight_gradient_schedules_agree(dev):
         torch.cuda.synchronize()
         results[name] = {k: g.cpu().numpy().copy() for k, g in grads.items()}
         del eng
-    for name in ("default", "no side stream", "no riders", "ln recompute"):
+    for name in ("default", "no side stream", "no riders", "ln recompute", "chained recurrences"):
         worst = min((O.agreement_db(results[name][k], results["plain"][k]), k) for k in results["plain"])
         assert worst[0] > 90, (name, worst)
 
