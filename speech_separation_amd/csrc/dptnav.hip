@@ -88,6 +88,7 @@ struct dptnav_ctx {
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
+  bool opt_debug_sync = false;      // debugging aid: name every launch class on stderr and synchronise behind it
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
   DropCfg drop_cfg(int block, int path, bool train, int half = 0) const {
@@ -203,7 +204,9 @@ struct ProfScope {
   dptnav_ctx* c;
   hipStream_t st;
   ProfRec rec;
-  ProfScope(dptnav_ctx* c_, int cat, hipStream_t st_) : c(c_), st(st_) {
+  int cat_;
+  ProfScope(dptnav_ctx* c_, int cat, hipStream_t st_) : c(c_), st(st_), cat_(cat) {
+    if (c->opt_debug_sync) fprintf(stderr, "[dptnav] -> %s\n", kProfNames[cat]);
     if (!c->prof_on) return;
     rec.cat = cat;
     rec.a = c->prof_event();
@@ -211,6 +214,10 @@ struct ProfScope {
     hipEventRecord(rec.a, st);
   }
   ~ProfScope() {
+    if (c->opt_debug_sync) {   // debugging aid (option debug_sync): wait for the launch and say how it ended
+      const hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, "[dptnav] <- %s: %s\n", kProfNames[cat_], hipGetErrorString(e));
+    }
     if (!c->prof_on) return;
     hipEventRecord(rec.b, st);
     c->prof_pending.push_back(rec);
@@ -357,6 +364,7 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
 
 #define LAUNCH_CHECK(c, what)                                                                  \
   do {                                                                                          \
+    if ((c)->opt_debug_sync) fprintf(stderr, "[dptnav] launched %s\n", what);                   \
     hipError_t e_ = hipGetLastError();                                                          \
     if (e_ != hipSuccess) return (c)->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); \
   } while (0)
@@ -2175,6 +2183,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "train_overlap") h->opt_train_overlap = value != 0;
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
   else if (k == "inject_fail") h->opt_inject_fail = value;
+  else if (k == "debug_sync") h->opt_debug_sync = value != 0;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }
