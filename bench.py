@@ -8,8 +8,7 @@
 A "step" = one forward of the whole hot path (libdptnav: head -> 12 TransformerDPRNN -> tail) over one batch of
 16 synthetic 2-speaker mixtures (T = 32000 samples = 4 s @ 8 kHz) PER GPU, inputs already resident in HBM.
 Mixtures are independent, so ranks shard by batch with no data-path collective (weak scaling); the only
-collectives are the timing barrier and a MAX over ranks of the elapsed time.  (--graph: EXPERIMENT, the timed steps replay
-the forward as a captured hipGraph, engine.ForwardGraph; not the default)
+collectives are the timing barrier and a MAX over ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line: the contract fields plus
   "roofline"      -- the DOMINANT kernel class = the one with the largest device time per step in this very run
@@ -330,25 +329,7 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
     return rows
 
 
-def make_step(eng, mix, e1, e2, out, graph: bool):
-    """One forward as a callable: the hipGraph replay of the captured forward (engine.ForwardGraph; default) or the eager
-    enqueue.  -> (step, "hipGraph replay" | "eager", ForwardGraph | None).  A failing capture falls back to eager and
-    says so."""
-    if graph:
-        try:
-            B, T = mix.shape
-            fg = eng.capture_forward(int(B), int(T), 1 if e1 is None else int(e1.shape[-1]))
-            fg.mix.copy_(mix)
-            if e1 is not None:
-                fg.e1.copy_(e1)
-                fg.e2.copy_(e2)
-            return fg.replay, "hipGraph replay", fg
-        except Exception as e:      # noqa: BLE001
-            log(f"hipGraph capture failed, eager launches instead: {e!r}")
-    return (lambda: eng.forward(mix, e1, e2, out=out)), "eager", None
-
-
-def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: int = 0, graph: bool = False):
+def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: int = 0):
     """A short, self-contained measurement of one forward configuration on this rank (N=1 legs of the headline line):
     mixtures/s, whole-path fraction of the fp32-MFMA peak and its dominant kernel's figures."""
     cfg, B_default, T, workload = CONFIGS[config]
@@ -360,17 +341,14 @@ def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: i
     e1 = torch.from_numpy(inp["s1_embedding"]).to(dev) if not cfg.audio_only else None
     e2 = torch.from_numpy(inp["s2_embedding"]).to(dev) if not cfg.audio_only else None
     out = (torch.empty_like(mix), torch.empty_like(mix))
-    step, launch, fg = make_step(eng, mix, e1, e2, out, graph)
     for _ in range(warmup):
-        step()
+        eng.forward(mix, e1, e2, out=out)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        eng.forward(mix, e1, e2, out=out)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    if fg is not None:
-        out = fg.out
     eng.profile(True)
     eng.profile_reset()
     for _ in range(psteps):
@@ -380,7 +358,7 @@ def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: i
     rows = kernel_rows(cfg, eng, prof, psteps, B, T, dev)
     tf = B / dt * eng.flops_per_mixture(T) / 1e12
     res = {"workload": f"{workload}, batch={B}, T={T}", "value": round(B / dt, 3), "unit": "mixtures/sec",
-           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup, "launch": launch,
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
            "gflop_per_mixture": round(eng.flops_per_mixture(T) / 1e9, 1),
            "whole_path_tflops": round(tf, 2), "whole_path_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
            "dominant_kernel": {k: rows[0][k] for k in ("class", "kernel", "launches_per_step", "launch_ms", "ms_per_step", "achieved", "frac")
@@ -392,7 +370,7 @@ def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: i
     return res
 
 
-def latency_leg(dev, calls: int = 10, graph: bool = False):
+def latency_leg(dev, calls: int = 10):
     """The reference's OWN perf protocol (profiler.py:25-37,62-65: bs = 1, one 32000-sample mixture, 1 warm-up, 10 timed
     calls, mean / std of the call time) restated for this path: DPTN-AV alone (the lip-reading front end is outside the
     path: BASELINE configs[2] says precomputed embeddings), every call bracketed by a device synchronisation (the
@@ -414,15 +392,12 @@ def latency_leg(dev, calls: int = 10, graph: bool = False):
             torch.cuda.synchronize(dev)
             ts.append(1e3 * (time.perf_counter() - t0))
         return ts
-    eager = timed(lambda: eng.forward(mix, e1, e2, out=out))
-    step, launch, fg = make_step(eng, mix, e1, e2, out, graph)
-    times = timed(step) if fg is not None else eager
+    times = timed(lambda: eng.forward(mix, e1, e2, out=out))
     res = {"what": "profiler.py protocol (bs = 1, T = 32000): one DPTN-AV forward, synchronised per call", "calls": calls,
-           "launch": launch, "mean_ms": round(float(np.mean(times)), 3), "std_ms": round(float(np.std(times)), 3),
-           "min_ms": round(min(times), 3), "eager_mean_ms": round(float(np.mean(eager)), 3),
+           "mean_ms": round(float(np.mean(times)), 3), "std_ms": round(float(np.std(times)), 3), "min_ms": round(min(times), 3),
            "serial_lstm_steps": 6 * (cfg.chunk_size + eng.chunks(T)),
            "reference_published": "0.09989 s mean / 0.04486 s std on a Kaggle P100, lip-reader included, no device sync (README.md:116-117)"}
-    del eng, out, fg, step
+    del eng, out
     torch.cuda.empty_cache()
     return res
 
@@ -488,9 +463,6 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short configs[1] / configs[4] legs that the "
                     "default N=1 headline run appends as `other_configs`")
     ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision experiment leg")
-    ap.add_argument("--graph", action="store_true", help="EXPERIMENT: the timed steps replay the forward as a captured hipGraph "
-                    "(engine.ForwardGraph) instead of enqueueing it launch by launch; off by default -- see DESIGN.md section 6.4 "
-                    "(a GPU memory fault was seen with graph replay at B = 1 when host buffers were freed between replays)")
     ap.add_argument("--pmc-run", action="store_true", help="warm-up + timed steps only (no per-kernel event pass, no isolated "
                     "pass, no CPU leg): the command rocprofv3 --pmc / --kernel-trace passes are taken over")
     args = ap.parse_args()
@@ -525,32 +497,20 @@ def main():
     out = (torch.empty_like(mix), torch.empty_like(mix))
 
     log(f"rank {env.rank}/{env.world} on {dev}: warm-up")
-    step, launch, fg = make_step(eng, mix, e1, e2, out, args.graph and not args.pmc_run)
     for _ in range(args.warmup):
-        step()
+        eng.forward(mix, e1, e2, out=out)
     env.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        eng.forward(mix, e1, e2, out=out)
     torch.cuda.synchronize(dev)
     env.barrier()
     torch.cuda.synchronize(dev)
     mine = time.perf_counter() - t0
     elapsed = env.max_over_ranks(mine)
     per_rank_s = env.gather_over_ranks(mine)
-    log(f"timed region: {args.steps} steps in {elapsed:.3f} s ({launch})")
-    eager_ms = None
-    if fg is not None:        # the same steps enqueued launch by launch, for the record
-        for _ in range(2):
-            eng.forward(mix, e1, e2, out=out)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(min(args.steps, 10)):
-            eng.forward(mix, e1, e2, out=out)
-        torch.cuda.synchronize(dev)
-        eager_ms = 1e3 * (time.perf_counter() - t1) / min(args.steps, 10)
-        assert torch.equal(fg.out[0], out[0]) and torch.equal(fg.out[1], out[1]), "graph replay differs from the eager forward"
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     if args.pmc_run:
         if env.rank == 0:
             print(json.dumps({"pmc_run": True, "config": args.config, "steps": args.steps, "warmup": args.warmup,
@@ -623,9 +583,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}, batch={B} per GPU, T={T}, random-init weights (numpy seed 0)",
                        "batch_per_gpu": B, "samples": T, "tokens_per_mixture": S * K,
-                       "parallelism": f"dp{env.world} (batch shards, no data-path collective)",
-                       "launch": launch},
-            "eager_ms_per_step": round(eager_ms, 4) if eager_ms is not None else None,
+                       "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "class": dom["class"], "achieved": dom["achieved"],
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": dom["traffic"], "traffic_unit": traffic_unit,
@@ -647,14 +605,13 @@ def main():
             "backend": env.backend, "rccl_ranks": env.backend_world() if env.backend == "nccl" else 0,
             "per_rank_mixtures_per_sec": [round(B * args.steps / t, 3) for t in per_rank_s],
         }
-        del eng, out, mix, e1, e2, fg, step
+        del eng, out, mix, e1, e2
         torch.cuda.empty_cache()
-        g = args.graph
         if not args.no_other_configs:
             line["other_configs"] = {
-                "dptn_audio": optional_leg("other_configs.dptn_audio", forward_leg, "dptn_audio", dev, steps=10, warmup=3, psteps=3, graph=g),
-                "dprnn_av": optional_leg("other_configs.dprnn_av", forward_leg, "dprnn_av", dev, steps=3, warmup=1, psteps=1, graph=g)}
-            line["latency_b1"] = optional_leg("latency_b1", latency_leg, dev, graph=g)
+                "dptn_audio": optional_leg("other_configs.dptn_audio", forward_leg, "dptn_audio", dev, steps=10, warmup=3, psteps=3),
+                "dprnn_av": optional_leg("other_configs.dprnn_av", forward_leg, "dprnn_av", dev, steps=3, warmup=1, psteps=1)}
+            line["latency_b1"] = optional_leg("latency_b1", latency_leg, dev)
         if not args.no_train_step:
             line["train_step"] = optional_leg("train_step", train_step_leg, cfg, dev, T)
         if env.world == 1 and not args.no_cpu_baseline:

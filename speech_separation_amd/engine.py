@@ -201,11 +201,6 @@ class DptnEngine:
             self._raise(rc, "dptnav_forward")
         return s1, s2
 
-    def capture_forward(self, B: int, T: int, Tv: int = 50) -> "ForwardGraph":
-        """The forward of a (B, T, Tv) batch as a hipGraph (ForwardGraph below): one replay per call instead of ~130 launches
-        and events enqueued from the host."""
-        return ForwardGraph(self, B, T, Tv)
-
     # ------------------------------------------------------------------ training step, path level
     def bind_grads(self) -> Dict[str, torch.Tensor]:
         """Allocate the gradient buffers the library WRITES and bind them; returns {key: tensor}.  All of them are views
@@ -414,59 +409,6 @@ class DptnEngine:
             self._raise(rc, "dptnav_workspace_tap")
         ws = self._workspace(B, T, Tv)
         return ws[off.value:off.value + 4 * n.value].view(torch.float32)
-
-
-class ForwardGraph:
-    """EXPERIMENTAL (not used by the drop-in modules, bench.py only with --graph): a GPU memory access fault was observed with
-    graph replay at B = 1 when the caller freed host (numpy) buffers between replays -- timing dependent, gone under
-    AMD_LOG_LEVEL=4, never seen at B >= 2 or with eager launches; not understood.  Do not use in
-    production.
-
-    dptnav_forward of one batch shape captured ONCE as a hipGraph (stream capture through torch.cuda.graph: the library's
-    launches, its memsets and the fork / join events of its internal streams all become graph nodes) and replayed per call.
-    What it buys: the host no longer enqueues ~45 (B = 1) to ~135 (B = 16) launches per forward -- 9.63 -> 9.26 ms for a
-    single mixture, 23.0 -> 12.8 ms at B = 4 and 36.9 -> 30.0 ms at B = 16 when every call is synchronised (serving), 1-2 %
-    when forwards are enqueued back to back.  The graph owns static input / output buffers and its own workspace:
-      g = engine.capture_forward(B, T, Tv);  s1, s2 = g(mix, e1, e2)        # copies in, replays, returns the STATIC outputs
-    (they are overwritten by the next call: clone them to keep them).  It bakes in the engine's options and the pointers of
-    the bound weights: in-place weight updates are seen by the next replay, re-bound weights need a new capture."""
-
-    def __init__(self, eng: "DptnEngine", B: int, T: int, Tv: int = 50):
-        cfg, dev = eng.cfg, eng.device
-        self.eng, self.shape = eng, (B, T, Tv)
-        self._bound_ptrs = eng._bound_ptrs
-        self.mix = torch.zeros(B, T, device=dev)
-        av = not cfg.audio_only
-        self.e1 = torch.zeros(B, cfg.video_emb_size, Tv, device=dev) if av else None
-        self.e2 = torch.zeros(B, cfg.video_emb_size, Tv, device=dev) if av else None
-        self.out = (torch.empty(B, T, device=dev), torch.empty(B, T, device=dev))
-        self.ws = torch.empty(eng.workspace_bytes(B, T, Tv if av else 1), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):          # warm-up outside the capture: function attributes, internal streams
-                eng.forward(self.mix, self.e1, self.e2, out=self.out, ws=self.ws)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                eng.forward(self.mix, self.e1, self.e2, out=self.out, ws=self.ws)
-
-    def replay(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        if self.eng._bound_ptrs != self._bound_ptrs:
-            raise RuntimeError("the engine's weights were re-bound after this graph was captured: capture again")
-        self.graph.replay()
-        return self.out
-
-    def __call__(self, mix: torch.Tensor, e1: Optional[torch.Tensor] = None, e2: Optional[torch.Tensor] = None):
-        if tuple(mix.shape) != tuple(self.mix.shape):
-            raise ValueError(f"captured for mix {tuple(self.mix.shape)}, got {tuple(mix.shape)}")
-        self.mix.copy_(mix)
-        if self.e1 is not None:
-            if e1 is None or e2 is None or tuple(e1.shape) != tuple(self.e1.shape) or tuple(e2.shape) != tuple(self.e2.shape):
-                raise ValueError(f"captured for embeddings {tuple(self.e1.shape)}")
-            self.e1.copy_(e1)
-            self.e2.copy_(e2)
-        return self.replay()
 
 
 def params_to_device(sd: Mapping[str, "object"], device) -> Dict[str, torch.Tensor]:
