@@ -252,6 +252,66 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   }
 }
 
+// The same contraction for shapes wgrad_kernel is not built for (NN a multiple of 32 but not of 128: the 64-feature models'
+// out-projection 64 x 64, ffn 64 x 256, in-projection 192 x 64): dW[NN][KK] = sum_tokens Y^T X with the (NN/32) x (KK/32)
+// output blocks dealt round robin to the four waves, 32-token tiles through LDS, a grid-stride loop instead of tickets and
+// the partial tile written ROW-MAJOR (slab_reduce_kernel sums it).  Plain rather than tuned: these shapes are not on a
+// BASELINE configuration's training path.
+template <int NN, int KK, class YLoad, class XLoad>
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(int ntiles, YLoad yl, XLoad xl, float* __restrict__ slab) {
+  static_assert(NN % 32 == 0 && KK % 32 == 0, "wgrad tile");
+  constexpr int LDY = NN + 4, LDX = KK + 4, RBT = NN / 32, CBT = KK / 32, NBLK = RBT * CBT, NBW = (NBLK + 3) / 4;
+  constexpr int Y4 = NN / 4, X4 = KK / 4, NY = (32 * Y4) / 256, NX = (32 * X4) / 256;
+  static_assert((32 * Y4) % 256 == 0 && (32 * X4) % 256 == 0, "staging map");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ys = smem;
+  float* Xs = Ys + 32 * LDY;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
+  f32x16 acc[NBW];
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) acc[k] = zero16();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float4 py[NY], px[NX];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) py[i] = wg_load(yl, tile, (i * 256 + tid) / Y4, (i * 256 + tid) % Y4);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) px[i] = wg_load(xl, tile, (i * 256 + tid) / X4, (i * 256 + tid) % X4);
+    __syncthreads();                                   // previous tile's fragments fully consumed
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * LDY + 4 * (idx % Y4)]) = py[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = i * 256 + tid;
+      *reinterpret_cast<float4*>(&Xs[(idx / X4) * LDX + 4 * (idx % X4)]) = px[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+      const int blk = w + 4 * k;                       // wave-uniform
+      if (blk < NBLK) {
+        const int rb = blk / CBT, cb = blk % CBT;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)                   // MFMA step s covers tokens 2 s (slot 0) and 2 s + 1 (slot 1)
+          acc[k] = mfma32(Ys[(2 * s + hh) * LDY + rb * 32 + c], Xs[(2 * s + hh) * LDX + cb * 32 + c], acc[k]);
+      }
+    }
+  }
+  float* out = slab + (size_t)blockIdx.x * (NN * KK);
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) {
+    const int blk = w + 4 * k;
+    if (blk < NBLK) {
+      const int rb = blk / CBT, cb = blk % CBT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(size_t)(rb * 32 + ROW32(r, hh)) * KK + cb * 32 + c] = acc[k][r];
+    }
+  }
+}
+
 // Two weight gradients that share their Y operand in ONE pass over Y:  dWa = sum Y^T Xa,  dWb = sum Y^T Xb  (the LSTM's
 // W_ih and W_hh gradients: Y = dP, Xa = the layer input, Xb = h_{t-1}).  The Y tile is staged and its fragments are
 // read once for 2 x CB MFMAs each; 2 x RB x CB accumulator tiles per wave (256 registers for <256,128>: they live in

@@ -582,7 +582,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   if (dptn && !fused) {
     ALoadDense al{att, M, N, BM};
     bool done = false;
-    if constexpr (N == 128) {
+    {
       if (pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
         EpiBiasResLNSave<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM, pb.zn1, pb.rs1};
         if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm (tape)", w.out_w, ntiles, 1, al, ep)) return rc;
@@ -676,7 +676,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     } else if (w.ndir == 2 && pb.train) {
       ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, BM};
       bool done = false;
-      if constexpr (N == 128) {
+      {
         if (pb.zn2) {
           EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
           if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
@@ -916,6 +916,28 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
   return DPTNAV_OK;
 }
 
+// the same for the shapes wgrad_kernel is not built for (NN not a multiple of 128): wgrad_generic_kernel, row-major partial
+// tiles summed by slab_reduce_kernel; the bias gradient (column sums of Y) is a separate pass over Y (launch_colsum below)
+template <int NN, int KK, class YL, class XL>
+int launch_wgrad_generic(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, const YL& yl, const XL& xl, float* grad) {
+  const size_t lds = sizeof(float) * 32 * (size_t)((NN + 4) + (KK + 4));
+  const int grid = cap_grid(ntiles, br.pl.slab_wgs);
+  float* slab = br.ws + br.pl.slab;
+  static_assert((size_t)NN * KK <= 512 * 128, "slab size");
+  auto kern = wgrad_generic_kernel<NN, KK, YL, XL>;
+  static PerDeviceOnce ready;
+  if (!ready.done(c->device_id)) {
+    if (int rc = set_lds(c, kern, lds, what)) return rc;
+    ready.set(c->device_id);
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, yl, xl, slab);
+  LAUNCH_CHECK(c, what);
+  constexpr int64_t count = (int64_t)NN * KK;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((count + 31) / 32)), dim3(256), 0, br.st, slab, grid, count, grad, 0);
+  LAUNCH_CHECK(c, what);
+  return DPTNAV_OK;
+}
+
 // sums of the partial tiles / column sums a WgradRider launch (launch_gemm) left in the slab region
 template <int NN, int KK>
 int reduce_rider(dptnav_ctx* c, BwdRun& br, const char* what, int grid, int col_after, float* grad, float* bias_grad) {
@@ -981,7 +1003,10 @@ template <int N>
 int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const float* x_in, const float* d_out,
                       float* d_in, int B, int S, float* tape, const PathTape& tp) {
   constexpr int GROUP = N / 4, DH = N / 4;
-  static_assert(N == 128, "the training step is built for num_features = 128 (BASELINE config 4)");
+  // N = 128 (BASELINE config 4): the tuned kernels (weight-gradient riders, wgrad2, fragment-order partial tiles);  N = 64
+  // (DPTNWavEncDec): the same chain with the generic weight-gradient kernel where a tuned shape does not exist and
+  // 64-row x 64-column tiles for the data-gradient GEMMs whose output is N wide
+  constexpr int WRn = N == 128 ? 1 : 2, WCn = N == 128 ? 4 : 2, BMn = 32 * WRn;
   const dptnav_config& g = c->cfg;
   const PathWeights& w = c->pw[2 * block + path];
   const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
@@ -995,7 +1020,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         *cst = tape + tp.cst;
   float *DZ = br.ws + br.pl.dz, *DHb = br.ws + br.pl.dh, *DG = br.ws + br.pl.dg, *DY1 = br.ws + br.pl.dy1,
         *DATT = br.ws + br.pl.datt, *DQKV = br.ws + br.pl.dqkv, *LNP = br.ws + br.pl.lnp;
-  const int64_t ntiles = (M + 31) / 32;
+  const int64_t ntiles = (M + 31) / 32, ntiles_n = (M + BMn - 1) / BMn;
   Run run;   // the GEMM engine takes its ticket counters from a Run: alias it onto the backward workspace
   run.ws = br.ws;
   run.pl = Plan{};
@@ -1016,6 +1041,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   };
   if (tp.zn2) {
     if (!ln_from_tape(d_out, tape + tp.zn2, tape + tp.rs2, w.ln2_w, "ln2.weight", "ln2.bias")) return c->fail(DPTNAV_ERR_HIP, "ln2 backward");
+  } else if constexpr (N != 128) {
+    return c->fail(DPTNAV_ERR_INVALID, "training with num_features = %d needs option ln_tape = 1", N);
   } else {
     ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, 32};
     EpiLNBackward<GROUP, 0> ep{DZ, w.ffn_b, y1, w.ln2_w, d_out, LNP, M, N, 32};
@@ -1029,27 +1056,37 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   br.slot = run.slot;
   // 2 + 3. ffn parameter gradients and d h = (dz2 W_f) masked by the ReLU.  Option wgrad_ride (default): ONE launch -- the
   //        data-gradient GEMM stages the dz2 tile anyway and forms dW_f / db_f on the side (WgradRider, gemm_ws.h)
-  if (c->opt_wgrad_ride) {
-    run.slot = br.slot;
-    ALoadDense al{DZ, M, N, 32};
-    EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
-    float* slab = br.ws + br.pl.slab;
-    int rgrid = 0;
-    // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
-    WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
-                                                   slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
-    if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
-                                                      2 * LSTM_H, &rgrid, rd))
-      return rc;
-    br.slot = run.slot;
-    if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
-      return rc;
-  } else {
+  bool rode = false;
+  if constexpr (N == 128) {
+    if (c->opt_wgrad_ride) {
+      rode = true;
+      run.slot = br.slot;
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+      float* slab = br.ws + br.pl.slab;
+      int rgrid = 0;
+      // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
+      WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
+                                                     slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
+      if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
+                                                        2 * LSTM_H, &rgrid, rd))
+        return rc;
+      br.slot = run.slot;
+      if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
+        return rc;
+    }
+  }
+  if (!rode) {
     {
       ALoadCols yl{DZ, M, N, 0, 32};
       ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
-      if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
-        return rc;
+      if constexpr (N == 128) {
+        if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
+          return rc;
+      } else {
+        if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
+        if (int rc = launch_colsum<N>(c, br, "d ffn bias", DZ, M, N, 0, G("ffn.1.bias"))) return rc;
+      }
     }
     run.slot = br.slot;
     {
@@ -1064,7 +1101,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   const bool use16 = lstm_use16(c, geom, 2, M);
   const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;   // workgroups per direction = partial bias rows
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
-  const bool side = br.side != nullptr && c->opt_wgrad2;
+  const bool wg2 = c->opt_wgrad2 && N == LSTM_H;        // wgrad2 pairs two X operands of equal width
+  const bool side = br.side != nullptr && wg2;
   if (side) {   // this path's dP goes to the buffer the weight gradients of two paths ago have (or will have) read
     if (br.dg_sel) DG = br.ws + (br.dg_sel == 1 ? br.pl.dg2 : br.pl.dg3);
     if (br.wg_pending[br.dg_sel] && hipStreamWaitEvent(st, br.ev_wg[br.dg_sel], 0) != hipSuccess)
@@ -1094,47 +1132,63 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
       const ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
-      if (c->opt_wgrad2) {   // W_ih and W_hh gradients in ONE pass over dP; the four (direction, half) slices in one launch
-        static_assert(N == LSTM_H, "wgrad2 pairs two operands of equal width");
-        const int s4 = 2 * d + half;
-        wa.yl[s4] = yl;
-        wa.xa[s4] = xl;
-        wa.xb[s4] = hl;
-        gA[s4] = G(wih.c_str()) + half * 256 * N;
-        gB[s4] = G(whh.c_str()) + half * 256 * LSTM_H;
+      if (wg2) {   // W_ih and W_hh gradients in ONE pass over dP; the four (direction, half) slices in one launch
+        if constexpr (N == LSTM_H) {
+          const int s4 = 2 * d + half;
+          wa.yl[s4] = yl;
+          wa.xa[s4] = xl;
+          wa.xb[s4] = hl;
+          gA[s4] = G(wih.c_str()) + half * 256 * N;
+          gB[s4] = G(whh.c_str()) + half * 256 * LSTM_H;
+        }
       } else {
         if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
         if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
       }
     }
   }
-  if (c->opt_wgrad2) {
-    if (side) {
-      if (hipEventRecord(br.ev_bptt, st) != hipSuccess || hipStreamWaitEvent(br.side, br.ev_bptt, 0) != hipSuccess)
-        return c->fail(DPTNAV_ERR_HIP, "side stream fork");
-      unsigned* side_q = br.take_queue_side(4);
-      if (!side_q) return c->fail(DPTNAV_ERR_INVALID, "d w_ih + d w_hh: side-stream ticket counters exhausted");
-      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, br.side, br.ws + br.pl.slab2, side_q))
-        return rc;
-      if (hipEventRecord(br.ev_wg[br.dg_sel], br.side) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream record");
-      br.wg_pending[br.dg_sel] = true;
-      br.dg_sel = (br.dg_sel + 1) % 3;
-    } else {
-      if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, br.take_queue(4)))
-        return rc;
+  if constexpr (N == LSTM_H) {
+    if (wg2) {
+      if (side) {
+        if (hipEventRecord(br.ev_bptt, st) != hipSuccess || hipStreamWaitEvent(br.side, br.ev_bptt, 0) != hipSuccess)
+          return c->fail(DPTNAV_ERR_HIP, "side stream fork");
+        unsigned* side_q = br.take_queue_side(4);
+        if (!side_q) return c->fail(DPTNAV_ERR_INVALID, "d w_ih + d w_hh: side-stream ticket counters exhausted");
+        if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, br.side, br.ws + br.pl.slab2, side_q))
+          return rc;
+        if (hipEventRecord(br.ev_wg[br.dg_sel], br.side) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream record");
+        br.wg_pending[br.dg_sel] = true;
+        br.dg_sel = (br.dg_sel + 1) % 3;
+      } else {
+        if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, br.take_queue(4)))
+          return rc;
+      }
     }
   }
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
   run.slot = br.slot;
   for (int d = 0; d < 2; ++d) {
-    ALoadCols al{DG, M, 2 * 512, d * 512, 32};
-    EpiAddMaskStoreT<true, false> ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
-    if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
-      return rc;
+    if constexpr (N == 128) {
+      ALoadCols al{DG, M, 2 * 512, d * 512, 32};
+      EpiAddMaskStoreT<true, false> ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
+      if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
+        return rc;
+    } else {
+      // 64-row tiles: a 64 x 512 A tile (double buffered) does not fit the LDS, so the gate columns go in two halves
+      for (int half = 0; half < 2; ++half) {
+        ALoadCols al{DG, M, 2 * 512, d * 512 + half * 256, BMn};
+        EpiAddMaskStoreT<true, false> ep{DY1, d == 0 && half == 0 ? DZ : DY1, nullptr, M, N, BMn, N};
+        if (int rc = launch_gemm<256, 1, WRn, WCn, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d] + (size_t)half * 256 * N, ntiles_n, 1,
+                                                         al, ep, nullptr, N))
+          return rc;
+      }
+    }
   }
   // 7. push d y1 through LayerNorm 1 (tape, or recompute z1 = att W_o^T + b_o + x)
   if (tp.zn1) {
     if (!ln_from_tape(DY1, tape + tp.zn1, tape + tp.rs1, w.ln1_w, "ln1.weight", "ln1.bias")) return c->fail(DPTNAV_ERR_HIP, "ln1 backward");
+  } else if constexpr (N != 128) {
+    return c->fail(DPTNAV_ERR_INVALID, "training with num_features = %d needs option ln_tape = 1", N);
   } else {
     ALoadDense al{att, M, N, 32};
     EpiLNBackward<GROUP, 0> ep{DZ, w.out_b, x_in, w.ln1_w, DY1, LNP, M, N, 32};
@@ -1147,32 +1201,42 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   br.slot = run.slot;
   // 8. out-projection gradients and d att (one launch with option wgrad_ride, as in 2 + 3)
-  if (c->opt_wgrad_ride) {
-    run.slot = br.slot;
-    ALoadDense al{DZ, M, N, 32};
-    EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
-    float* slab = br.ws + br.pl.slab;
-    int rgrid = 0;
-    WgradRider<N, ALoadDense, true> rd{ALoadDense{att, M, N, 32}, slab, slab + (size_t)BWD_SLAB_WGS * N * N, M};
-    if (int rc = launch_gemm<N, 1, 1, 4, true, false>(c, run, CAT_OUTPROJ, "d att + d out weight", w.out_w, ntiles, 1, al, ep,
-                                                      nullptr, N, &rgrid, rd))
-      return rc;
-    br.slot = run.slot;
-    if (int rc = reduce_rider<N, N>(c, br, "d out weight + bias", rgrid, BWD_SLAB_WGS, G("mha.out_proj.weight"), G("mha.out_proj.bias")))
-      return rc;
-  } else {
+  bool rode8 = false;
+  if constexpr (N == 128) {
+    if (c->opt_wgrad_ride) {
+      rode8 = true;
+      run.slot = br.slot;
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
+      float* slab = br.ws + br.pl.slab;
+      int rgrid = 0;
+      WgradRider<N, ALoadDense, true> rd{ALoadDense{att, M, N, 32}, slab, slab + (size_t)BWD_SLAB_WGS * N * N, M};
+      if (int rc = launch_gemm<N, 1, 1, 4, true, false>(c, run, CAT_OUTPROJ, "d att + d out weight", w.out_w, ntiles, 1, al, ep,
+                                                        nullptr, N, &rgrid, rd))
+        return rc;
+      br.slot = run.slot;
+      if (int rc = reduce_rider<N, N>(c, br, "d out weight + bias", rgrid, BWD_SLAB_WGS, G("mha.out_proj.weight"), G("mha.out_proj.bias")))
+        return rc;
+    }
+  }
+  if (!rode8) {
     {
       ALoadCols yl{DZ, M, N, 0, 32};
       ALoadDense xl{att, M, N, 32};
-      if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
-                                      G("mha.out_proj.bias")))
-        return rc;
+      if constexpr (N == 128) {
+        if (int rc = launch_wgrad<N, N>(c, br, "d out weight + bias", ntiles, yl, xl, G("mha.out_proj.weight"),
+                                        G("mha.out_proj.bias")))
+          return rc;
+      } else {
+        if (int rc = launch_wgrad_generic<N, N>(c, br, "d out weight", ntiles, yl, xl, G("mha.out_proj.weight"))) return rc;
+        if (int rc = launch_colsum<N>(c, br, "d out bias", DZ, M, N, 0, G("mha.out_proj.bias"))) return rc;
+      }
     }
     run.slot = br.slot;
     {
-      ALoadDense al{DZ, M, N, 32};
-      EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
-      if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+      ALoadDense al{DZ, M, N, BMn};
+      EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, BMn, N};
+      if (int rc = launch_gemm<N, 1, WRn, WCn, true>(c, run, CAT_OUTPROJ, "d att", w.out_w, ntiles_n, 1, al, ep, nullptr, N)) return rc;
     }
     br.slot = run.slot;
   }
@@ -1214,15 +1278,20 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   {
     ALoadCols yl{DQKV, M, 3 * N, 0, 32};
     ALoadDense xl{x_in, M, N, 32};
-    if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight + bias", ntiles, yl, xl, G("mha.in_proj_weight"),
-                                        G("mha.in_proj_bias")))
-      return rc;
+    if constexpr (N == 128) {
+      if (int rc = launch_wgrad<3 * N, N>(c, br, "d in weight + bias", ntiles, yl, xl, G("mha.in_proj_weight"),
+                                          G("mha.in_proj_bias")))
+        return rc;
+    } else {
+      if (int rc = launch_wgrad_generic<3 * N, N>(c, br, "d in weight", ntiles, yl, xl, G("mha.in_proj_weight"))) return rc;
+      if (int rc = launch_colsum<3 * N>(c, br, "d in bias", DQKV, M, 3 * N, 0, G("mha.in_proj_bias"))) return rc;
+    }
   }
   run.slot = br.slot;
   {
-    ALoadDense al{DQKV, M, 3 * N, 32};
-    EpiAddMaskStoreT<true, false> ep{d_in, DZ, nullptr, M, N, 32, N};
-    if (int rc = launch_gemm<3 * N, 1, 1, 4, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles, 1, al, ep, nullptr, N)) return rc;
+    ALoadDense al{DQKV, M, 3 * N, BMn};
+    EpiAddMaskStoreT<true, false> ep{d_in, DZ, nullptr, M, N, BMn, N};
+    if (int rc = launch_gemm<3 * N, 1, WRn, WCn, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles_n, 1, al, ep, nullptr, N)) return rc;
   }
   br.slot = run.slot;
   return DPTNAV_OK;
@@ -1858,8 +1927,7 @@ size_t dptnav_train_bwd_workspace_bytes(dptnav_handle h, int B, int S) {
 int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S,
                               void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
-    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture");
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !x_out || !tape)
     return h->fail(DPTNAV_ERR_INVALID, "train_path_forward: bad argument");
   PathTape tp;
@@ -1874,13 +1942,13 @@ int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float*
   float* tb = (float*)tape;
   PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true, tb + tp.astats};
   if (tp.zn1) { pb.zn1 = tb + tp.zn1; pb.rs1 = tb + tp.rs1; pb.zn2 = tb + tp.zn2; pb.rs2 = tb + tp.rs2; }
-  return run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb);
+  return h->cfg.num_features == 128 ? run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb)
+                                    : run_path<64>(h, run, block, path, x_in, x_out, B, S, &pb);
 }
 int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
                                int B, int S, void* tape, size_t tape_bytes, void* bws, size_t bws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
-    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture");
   if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !d_out || !d_in || !tape || !bws)
     return h->fail(DPTNAV_ERR_INVALID, "train_path_backward: bad argument");
@@ -1893,7 +1961,8 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
   BwdRun br{(float*)bws, bp, (hipStream_t)stream, 0, h->gptr.data()};
   if (hipMemsetAsync(br.ws + bp.queue, 0, QUEUE_SLOTS * sizeof(unsigned), br.st) != hipSuccess)
     return h->fail(DPTNAV_ERR_HIP, "ticket counter reset");
-  return run_path_backward<128>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp);
+  return h->cfg.num_features == 128 ? run_path_backward<128>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp)
+                                    : run_path_backward<64>(h, br, block, path, x_in, d_out, d_in, B, S, (float*)tape, tp);
 }
 
 // ---- training step, whole model -------------------------------------------------------------------------

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       // fragments are fetched in batches of 16 x ds_read_b128 BEFORE the MFMAs that use them: a read placed
       // between MFMAs is followed by s_waitcnt lgkmcnt(0) and exposes a full LDS round trip per k-chunk
       const float* arow = &Ab[(wr * 32 + c) * Sh::LDA + 4 * hh];
-      constexpr int CH = KIN / 8, BATCH = CH < 16 ? CH : 16;
+      // (KIN = 192, the in-projection data gradient of the 64-feature model: 24 chunks = 2 x 12)
+      constexpr int CH = KIN / 8, BATCH = CH < 16 ? CH : (CH % 16 == 0 ? 16 : (CH % 12 == 0 ? 12 : 8));
+      static_assert(CH % BATCH == 0, "fragment batches must tile the k chunks");
 #pragma unroll
       for (int m0 = 0; m0 < CH; m0 += BATCH) {
         float4 afr[BATCH];

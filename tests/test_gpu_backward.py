@@ -17,16 +17,24 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.mark.parametrize("features", [128, 64])
 @pytest.mark.parametrize("path", [0, 1])
-def test_path_backward_matches_autograd(dev, path):
+def test_path_backward_matches_autograd(dev, path, features):
+    """One TransformerDPRNN, forward with tape + backward, against fp64 autograd: num_features = 128 (DPTNAVWavEncDec, the
+    tuned kernels) and 64 (DPTNWavEncDec: generic weight-gradient kernel, 64 x 64 data-gradient tiles)."""
     from speech_separation_amd.engine import DptnEngine, params_to_device
-    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1, "dropout": 0.0})
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1, "dropout": 0.0, "num_features": features,
+                        "audio_only": features == 64})
     sd = synthetic_state_dict(cfg, seed=4)
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(sd, dev))
     grads = eng.bind_grads()
     B, S, K, N = 2, 3, cfg.chunk_size, cfg.num_features
-    rng = np.random.default_rng(1)
+    # (input seed: the FFN's ReLU has a kink at h = 0, and with 10^5 hidden values per direction the smallest |h| of a
+    #  draw is 1e-8..1e-6 -- below ~3e-8 fp32 and fp64 disagree on its sign and the gradient of that one unit differs by a
+    #  finite amount: seen with seed 1 at 64 features (|h| = 2.5e-8, one row of the LSTM gradients at 48 dB).  Seed 25
+    #  keeps every |h| above 4e-7 there; tools/ has no part in this, it is a property of the function)
+    rng = np.random.default_rng(1 if features == 128 else 25)
     x = rng.standard_normal((B, S, K, N)).astype(np.float32)
     dy = rng.standard_normal((B, S, K, N)).astype(np.float32)
 
