@@ -1328,6 +1328,7 @@ template <int N>
 int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const float* E, const float* Z,
                       const float* d_s1, const float* d_s2, float* d_x, int B, int64_t T, int64_t L, int S) {
   constexpr int GROUP = N / 4;
+  constexpr int WRn = N == 128 ? 1 : 2, WCn = N == 128 ? 4 : 2, BMn = 32 * WRn;   // tiles of the GEMMs whose output is N wide
   const dptnav_config& g = c->cfg;
   hipStream_t st = br.st;
   const int K = g.chunk_size, P = g.step_size;
@@ -1341,11 +1342,11 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   int grid = 0;
   // T2 recompute: q = OLA(Z) W_post^T + b_post + E ; d q, d decoder.weight
   {
-    ALoadOla al{Z, N, B, (int)L, S, K, P, left, ola, 32};
+    ALoadOla al{Z, N, B, (int)L, S, K, P, left, ola, BMn};
     EpiDecoderBwd<GROUP> ep{DQ, c->w("dprnn.postprocessing.0.bias"), E, c->w("decoder.weight"), d_s1, d_s2, LNP,
-                            (int64_t)B * L, T, (int)L, g.kernel_size_enc, c->stride, pad_left, 32};
-    if (int rc = launch_gemm<N, 1, 1, 4>(c, run, CAT_POST, "postproc recompute + decoder bwd",
-                                        c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32, 1, al, ep, nullptr, N, &grid))
+                            (int64_t)B * L, T, (int)L, g.kernel_size_enc, c->stride, pad_left, BMn};
+    if (int rc = launch_gemm<N, 1, WRn, WCn>(c, run, CAT_POST, "postproc recompute + decoder bwd",
+                                            c->w("dprnn.postprocessing.0.weight"), (rows + BMn - 1) / BMn, 1, al, ep, nullptr, N, &grid))
       return rc;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((N * 8 + 31) / 32), dim3(256), 0, st, LNP, grid, (int64_t)N * 8, slab, 0);
     hipLaunchKernelGGL(decoder_wgrad_finish_kernel, dim3((N * g.kernel_size_enc + 255) / 256), dim3(256), 0, st, slab,
@@ -1358,15 +1359,20 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   {
     ALoadCols yl{DQ, rows, N, 0, 32};
     ALoadOla xl{Z, N, B, (int)L, S, K, P, left, ola, 32};
-    if (int rc = launch_wgrad<N, N>(c, br, "d postproc weight", (rows + 31) / 32, yl, xl, G("dprnn.postprocessing.0.weight")))
-      return rc;
+    if constexpr (N == 128) {
+      if (int rc = launch_wgrad<N, N>(c, br, "d postproc weight", (rows + 31) / 32, yl, xl, G("dprnn.postprocessing.0.weight")))
+        return rc;
+    } else {
+      if (int rc = launch_wgrad_generic<N, N>(c, br, "d postproc weight", (rows + 31) / 32, yl, xl, G("dprnn.postprocessing.0.weight")))
+        return rc;
+    }
   }
   run.slot = br.slot;
   {
-    ALoadDense al{DQ, rows, N, 32};
-    EpiAddMaskStoreT<false, false> ep{DU, nullptr, nullptr, rows, N, 32, N};
-    if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_POST, "d u", c->w("dprnn.postprocessing.0.weight"), (rows + 31) / 32,
-                                              1, al, ep, nullptr, N))
+    ALoadDense al{DQ, rows, N, BMn};
+    EpiAddMaskStoreT<false, false> ep{DU, nullptr, nullptr, rows, N, BMn, N};
+    if (int rc = launch_gemm<N, 1, WRn, WCn, true>(c, run, CAT_POST, "d u", c->w("dprnn.postprocessing.0.weight"),
+                                                  (rows + BMn - 1) / BMn, 1, al, ep, nullptr, N))
       return rc;
   }
   br.slot = run.slot;
@@ -1382,10 +1388,10 @@ int run_tail_backward(dptnav_ctx* c, BwdRun& br, Run& run, const float* x, const
   }
   run.slot = br.slot;
   {
-    ALoadDense al{DZs, M, 2 * N, 32};
-    EpiPReLUBwd ep{d_x, x, c->w("dprnn.speakers_separation.0.weight"), LNP, M, N, 32};
-    if (int rc = launch_gemm<2 * N, 1, 1, 4, true>(c, run, CAT_SEP, "d prelu", c->w("dprnn.speakers_separation.1.weight"),
-                                                  (M + 31) / 32, 1, al, ep, nullptr, N, &grid))
+    ALoadDense al{DZs, M, 2 * N, BMn};
+    EpiPReLUBwd ep{d_x, x, c->w("dprnn.speakers_separation.0.weight"), LNP, M, N, BMn};
+    if (int rc = launch_gemm<2 * N, 1, WRn, WCn, true>(c, run, CAT_SEP, "d prelu", c->w("dprnn.speakers_separation.1.weight"),
+                                                      (M + BMn - 1) / BMn, 1, al, ep, nullptr, N, &grid))
       return rc;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, LNP, grid, (int64_t)1,
                        G("dprnn.speakers_separation.0.weight"), 0);
@@ -1967,8 +1973,9 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
 
 // ---- training step, whole model -------------------------------------------------------------------------
 static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, ModelTape* mt, BwdPlan* bp) {
-  if (h->cfg.arch != 0 || h->cfg.num_features != 128)
-    return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture with num_features = 128");
+  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture (DPRNN blocks: inference only)");
+  if (h->cfg.num_features != 128 && !h->opt_ln_tape)
+    return h->fail(DPTNAV_ERR_INVALID, "training step with num_features = %d needs option ln_tape = 1", h->cfg.num_features);
   if (!h->cfg.bidir) return h->fail(DPTNAV_ERR_INVALID, "training step: bidir = False not supported yet");
   if (int rc = make_plan(h, B, T, Tv, pl)) return rc;
   make_model_tape(h, B, pl->L, (int)pl->S, Tv, mt);
@@ -2066,8 +2073,9 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
     run[i].half = i;
     tb[i] = (float*)tape + sp.tape_off[i];
     const ModelTape& mt = sp.mt[i];
-    if (int rc = run_head<128>(h, run[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr, e2 ? e2 + b0[i] * Cv * Tv : nullptr,
-                               sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid))
+    if (int rc = (h->cfg.num_features == 128 ? run_head<128>(h, run[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr, e2 ? e2 + b0[i] * Cv * Tv : nullptr,
+                               sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid) : run_head<64>(h, run[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr, e2 ? e2 + b0[i] * Cv * Tv : nullptr,
+                               sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid)))
       return rc;
   }
   // the halves advance in lock step on the host; their recurrences are chained by events as in dptnav_forward
@@ -2083,16 +2091,18 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
       PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run[i].ws + sp.pl[i].pre, pt + mt.pt.hc, pt + mt.pt.gates,
                   pt + mt.pt.cst, true, pt + mt.pt.astats};
       if (mt.pt.zn1) { pb.zn1 = pt + mt.pt.zn1; pb.rs1 = pt + mt.pt.rs1; pb.zn2 = pt + mt.pt.zn2; pb.rs2 = pt + mt.pt.rs2; }
-      if (int rc = run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
-                                 tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb))
+      if (int rc = (h->cfg.num_features == 128 ? run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
+                                 tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb) : run_path<64>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
+                                 tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb)))
         return rc;
       have_prev = true;
     }
   // tail: Z (separation-conv output) is needed again by the backward -> kept on the tape
   for (int i = 0; i < sp.nhalf; ++i) {
     const ModelTape& mt = sp.mt[i];
-    if (int rc = run_tail<128>(h, run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, sp.Bh[i], T,
-                               s1 + b0[i] * T, s2 + b0[i] * T, tb[i] + mt.Z))
+    if (int rc = (h->cfg.num_features == 128 ? run_tail<128>(h, run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, sp.Bh[i], T,
+                               s1 + b0[i] * T, s2 + b0[i] * T, tb[i] + mt.Z) : run_tail<64>(h, run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, sp.Bh[i], T,
+                               s1 + b0[i] * T, s2 + b0[i] * T, tb[i] + mt.Z)))
       return rc;
   }
   return DPTNAV_OK;
@@ -2168,8 +2178,9 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
     dcur[i] = br[i].ws + bp.dxa;
     dnext[i] = br[i].ws + bp.dxb;
     const ModelTape& mt = sp.mt[i];
-    if (int rc = run_tail_backward<128>(h, br[i], run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, tb[i] + mt.Z,
-                                        d_s1 + b0[i] * T, d_s2 + b0[i] * T, dcur[i], sp.Bh[i], T, sp.pl[i].L, (int)sp.pl[i].S))
+    if (int rc = (h->cfg.num_features == 128 ? run_tail_backward<128>(h, br[i], run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, tb[i] + mt.Z,
+                                        d_s1 + b0[i] * T, d_s2 + b0[i] * T, dcur[i], sp.Bh[i], T, sp.pl[i].L, (int)sp.pl[i].S) : run_tail_backward<64>(h, br[i], run[i], tb[i] + mt.X0 + (size_t)(2 * nb) * mt.x_stride, tb[i] + mt.E, tb[i] + mt.Z,
+                                        d_s1 + b0[i] * T, d_s2 + b0[i] * T, dcur[i], sp.Bh[i], T, sp.pl[i].L, (int)sp.pl[i].S)))
       return rc;
   }
   bool have_prev = false;
@@ -2186,16 +2197,19 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
         br[i].lstm_record = h->ev_lstm[i];
       }
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
-      if (int rc = run_path_backward<128>(h, br[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride, dcur[i], dnext[i],
-                                          sp.Bh[i], (int)sp.pl[i].S, pt, mt.pt))
+      if (int rc = (h->cfg.num_features == 128 ? run_path_backward<128>(h, br[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride, dcur[i], dnext[i],
+                                          sp.Bh[i], (int)sp.pl[i].S, pt, mt.pt) : run_path_backward<64>(h, br[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride, dcur[i], dnext[i],
+                                          sp.Bh[i], (int)sp.pl[i].S, pt, mt.pt)))
         return rc;
       std::swap(dcur[i], dnext[i]);
       have_prev = true;
     }
   for (int i = 0; i < sp.nhalf; ++i)
-    if (int rc = run_head_backward<128>(h, br[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr,
+    if (int rc = (h->cfg.num_features == 128 ? run_head_backward<128>(h, br[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr,
                                         e2 ? e2 + b0[i] * Cv * Tv : nullptr, tb[i] + sp.mt[i].vid, dcur[i], sp.Bh[i], T,
-                                        sp.pl[i].L, (int)sp.pl[i].S, Tv))
+                                        sp.pl[i].L, (int)sp.pl[i].S, Tv) : run_head_backward<64>(h, br[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr,
+                                        e2 ? e2 + b0[i] * Cv * Tv : nullptr, tb[i] + sp.mt[i].vid, dcur[i], sp.Bh[i], T,
+                                        sp.pl[i].L, (int)sp.pl[i].S, Tv)))
       return rc;
   return DPTNAV_OK;
   };

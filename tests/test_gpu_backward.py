@@ -79,12 +79,13 @@ def test_path_backward_matches_autograd(dev, path, features):
 
 
 @pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
-@pytest.mark.parametrize("audio_only", [False, True])
-def test_whole_model_backward_matches_autograd(dev, audio_only, lstm_tile):
-    """d loss / d every parameter for a 2-block model: libdptnav train_forward/backward vs torch.autograd (fp64, CPU)."""
+@pytest.mark.parametrize("audio_only,features", [(False, 128), (True, 128), (True, 64)], ids=["av128", "audio128", "audio64"])
+def test_whole_model_backward_matches_autograd(dev, audio_only, features, lstm_tile):
+    """d loss / d every parameter for a 2-block model: libdptnav train_forward/backward vs torch.autograd (fp64, CPU).
+    audio64 = the reference's DPTNWavEncDec configuration (model/dptn_wav.yaml: 64 features)."""
     from speech_separation_amd.engine import DptnEngine, params_to_device
     from speech_separation_amd.spec import synthetic_inputs
-    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0, "audio_only": audio_only})
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0, "audio_only": audio_only, "num_features": features})
     sd = synthetic_state_dict(cfg, seed=2)
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(sd, dev))
@@ -351,7 +352,7 @@ def test_full_size_training_step_is_deterministic(dev):
 
 
 @pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
-@pytest.mark.parametrize("name,copies", [("grad_mid_av", 1), ("grad_full_av", 1), ("grad_full_av", 16)])
+@pytest.mark.parametrize("name,copies", [("grad_mid_av", 1), ("grad_full_av", 1), ("grad_full_av", 16), ("grad_mid_audio", 1)])
 def test_training_step_matches_reference_gradients(dev, golden, name, copies, lstm_tile):
     """BASELINE config 4 against the REFERENCE's own numbers: tests/golden/grad_*.npz hold the loss and d loss / d every
     parameter that the imported reference produced with `model.train(); outputs = model(**batch); SiSNRWavLoss;
@@ -360,7 +361,7 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     loss (dptnav_pit_sisnr_loss); the truth is the same reference step run in fp64.  `copies` = 16 repeats the fixture's one mixture over the batch of config 4
     (B=16 x T=32000, 6 blocks): the batch mean of 16 identical terms is the single term, so loss and gradients must
     reproduce the B=1 reference numbers while every kernel runs at its full BASELINE size (two halves, two streams)."""
-    from speech_separation_amd import DPTNAVWavEncDec
+    from speech_separation_amd import DPTNAVWavEncDec, DPTNWavEncDec
     from speech_separation_amd.spec import synthetic_inputs
     from speech_separation_amd.train import SiSNRWavLoss
     from tests.test_oracle_golden import reference_gradient_report
@@ -371,7 +372,12 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     sd = synthetic_state_dict(cfg, seed=wseed)
     assert weights_digest(sd) == str(z["digest"])
     kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
-    model = DPTNAVWavEncDec(**kw)
+    if cfg.audio_only:           # grad_mid_audio: the reference's DPTNWavEncDec (dptn_wav.py:64-126), 64 features
+        for k in ("video_emb_size", "hidden_video"):
+            kw.pop(k)
+        model = DPTNWavEncDec(**kw)
+    else:
+        model = DPTNAVWavEncDec(**kw)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).train()
     model._get_engine(dev).set_option("lstm16", 1 if lstm_tile == 16 else 0)

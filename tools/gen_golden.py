@@ -168,6 +168,8 @@ def gradient_fixtures(dptn_wav, losses, only):
         ("grad_tiny_av", DPTNConfig(**{**DPTN_TINY.to_dict(), "dropout": 0.0}), dict(B=2, T=209, Tv=9), 7, 11),
         ("grad_mid_av", DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0}), dict(B=2, T=8000, Tv=50), 0, 123),
         ("grad_full_av", DPTNConfig(**{**DPTN_AV.to_dict(), "dropout": 0.0}), dict(B=1, T=32000, Tv=50), 0, 123),
+        # the reference's audio-only DPTNWavEncDec (model/dptn_wav.yaml: 64 features), trainable here since round 3
+        ("grad_mid_audio", DPTNConfig(**{**DPTN_AUDIO.to_dict(), "num_blocks": 2, "dropout": 0.0}), dict(B=2, T=8000, Tv=50), 0, 123),
     ]
     for name, cfg, shp, wseed, iseed in cases:
         if only and name not in only:
