@@ -214,3 +214,29 @@ def test_train_step_with_a_frozen_parameter_or_kept_gradients_takes_the_stock_cl
         assert np.isfinite(float(st["loss"])) and float(st["grad_norm"]) > 0
     with pytest.raises(RuntimeError, match="not a view"):
         clip_grad_norm_(model2, 10.0)
+
+
+def test_audio_only_model_trains_with_the_fused_tail(dev):
+    """The reference's DPTNWavEncDec configuration (model/dptn_wav.yaml: 64 features, no video branch) through the whole
+    step -- forward with tape, device PIT SI-SNR loss, HIP backward, fused clip and FusedAdamW, attention dropout 0.1: the
+    loss goes down and nothing synchronises (its gradients are pinned to the reference's by
+    test_training_step_matches_reference_gradients[grad_mid_audio])."""
+    from speech_separation_amd import DPTNWavEncDec
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
+    model = DPTNWavEncDec(num_features=64, kernel_size_enc=7, hidden_dim=128, num_blocks=2, chunk_size=150, step_size=75,
+                          num_heads=4, dropout=0.1, bidir=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=6).items()})
+    model = model.to(dev).train()
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    inp = synthetic_inputs(model.cfg, B=4, T=6000, Tv=50, seed=9)
+    batch0 = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    first = train_step(model, dict(batch0), SiSNRWavLoss(), opt, 10.0)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        stats = [train_step(model, dict(batch0), SiSNRWavLoss(), opt, 10.0) for _ in range(4)]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    losses = [float(first["loss"])] + [float(s["loss"]) for s in stats]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(float(s["grad_norm"]) > 0 for s in stats)
