@@ -656,6 +656,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     if (w.ndir == 2 && split) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC, false, true>(c, run, CAT_FFN, "fc gemm (split)", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (w.ndir == 2 && pb.train && pb.zn2) {   // + zn / rstd on the tape for the LayerNorm backward
+      ALoadDense al{hc, M, 2 * LSTM_H, BM};
+      EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
+      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
     } else if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -800,17 +804,18 @@ int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
   const int64_t nst = std::max(((int64_t)B * S + 31) / 32 * K, ((int64_t)B * K + 31) / 32 * S);
   size_t o = 0;
   auto take = [&](size_t n) { size_t at = o; o += align64(n); return at; };
-  t->qkv = take((size_t)M * 3 * N);
-  t->att = take((size_t)M * N);
-  t->y1 = take((size_t)M * N);
+  const bool dptn = g.arch == 0;       // DPRNN blocks have no attention half: hc, gates, cell states and the LayerNorm rows only
+  t->qkv = take(dptn ? (size_t)M * 3 * N : 0);
+  t->att = take(dptn ? (size_t)M * N : 0);
+  t->y1 = take(dptn ? (size_t)M * N : 0);
   t->hc = take((size_t)(M + S * K) * 2 * H);
   t->gates = take((size_t)2 * nst * 512 * 32);
   t->cst = take((size_t)2 * nst * 128 * 32);
-  t->astats = take((size_t)M * g.num_heads * 2);
+  t->astats = take(dptn ? (size_t)M * g.num_heads * 2 : 0);
   t->zn1 = t->rs1 = t->zn2 = t->rs2 = 0;
   if (c->opt_ln_tape) {
-    t->zn1 = take((size_t)M * N);
-    t->rs1 = take((size_t)M);
+    t->zn1 = take(dptn ? (size_t)M * N : 64);      // (never 0: "zn1 != 0" is how the callers see that the LayerNorm tape is on)
+    t->rs1 = take(dptn ? (size_t)M : 0);
     t->zn2 = take((size_t)M * N);
     t->rs2 = take((size_t)M);
   }
@@ -999,6 +1004,111 @@ int launch_colsum(dptnav_ctx* c, BwdRun& br, const char* what, const float* Y, i
   return DPTNAV_OK;
 }
 
+// One DPRNN block half backward (IntraChunkRNN / InterChunkRNN, dprnn.py:24-47,65-89):
+//   forward   h = biLSTM(x);  v = h W_fc^T + b_fc;  out = LayerNorm(v) + x
+//   backward  dz = LayerNorm'(d_out)  [tape: zn, rstd];  dW_fc = dz^T h, db_fc = colsum dz;  dh = dz W_fc;  BPTT -> dP;
+//             dW_ih = dP^T x, dW_hh = dP^T h_{t-1}, db = colsum dP;  d_in = d_out (residual) + dP_f W_ih_f + dP_b W_ih_b
+// The kernels are the DPTN chain's (ln_backward_kernel, BPTT, weight gradients, data-gradient GEMMs); no attention half.
+template <int N>
+int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, const float* x_in, const float* d_out, float* d_in,
+                            int B, int S, float* tape, const PathTape& tp) {
+  constexpr int WRn = N == 128 ? 1 : 2, WCn = N == 128 ? 4 : 2, BMn = 32 * WRn;
+  const dptnav_config& g = c->cfg;
+  const PathWeights& w = c->pw[2 * block + path];
+  const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
+  auto G = [&](const char* leaf) { return br.gptr[c->slot(pre + leaf)]; };
+  if (w.ndir != 2) return c->fail(DPTNAV_ERR_INVALID, "training step: unidirectional inter-chunk LSTM not supported yet");
+  if (!tp.zn2) return c->fail(DPTNAV_ERR_INVALID, "training step of DPRNN blocks needs option ln_tape = 1");
+  const int K = g.chunk_size;
+  const int64_t M = (int64_t)B * S * K;
+  const SeqGeom geom = make_geom(path, B, S, K);
+  hipStream_t st = br.st;
+  float *hc = tape + tp.hc, *gates = tape + tp.gates, *cst = tape + tp.cst;
+  float *DZ = br.ws + br.pl.dz, *DHb = br.ws + br.pl.dh, *DG = br.ws + br.pl.dg, *LNP = br.ws + br.pl.lnp;
+  const int64_t ntiles = (M + 31) / 32, ntiles_n = (M + BMn - 1) / BMn;
+  Run run;
+  run.ws = br.ws;
+  run.pl = Plan{};
+  run.pl.queue = br.pl.queue;
+  run.st = st;
+  run.slot = br.slot;
+  // 1. LayerNorm backward from the tape
+  {
+    const int64_t npass = (M + (256 / (N / 4)) - 1) / (256 / (N / 4));
+    const int lgrid = (int)std::min<int64_t>(std::min<int64_t>(BWD_LNP_WGS, 4 * (int64_t)c->num_cus), (npass + 3) / 4);
+    ProfScope ps(c, CAT_FFN, st);
+    hipLaunchKernelGGL(ln_backward_kernel<N>, dim3(lgrid), dim3(256), 0, st, d_out, tape + tp.zn2, tape + tp.rs2, w.ln2_w, DZ, LNP, M);
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3((2 * N + 31) / 32), dim3(256), 0, st, LNP, lgrid, (int64_t)2 * N, G("norm1d.weight"),
+                       G("norm1d.bias"), N);
+    LAUNCH_CHECK(c, "norm1d backward");
+  }
+  // 2. fc gradients, d h = dz W_fc
+  {
+    ALoadCols yl{DZ, M, N, 0, 32};
+    ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32};
+    if constexpr (N == 128) {
+      if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d fc weight + bias", ntiles, yl, xl, G("fc.weight"), G("fc.bias"))) return rc;
+    } else {
+      if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d fc weight", ntiles, yl, xl, G("fc.weight"))) return rc;
+      if (int rc = launch_colsum<N>(c, br, "d fc bias", DZ, M, N, 0, G("fc.bias"))) return rc;
+    }
+  }
+  run.slot = br.slot;
+  {
+    ALoadDense al{DZ, M, N, 32};
+    EpiAddMaskStoreT<false, false> ep{DHb, nullptr, nullptr, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+    if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H)) return rc;
+  }
+  br.slot = run.slot;
+  // 3. LSTM backward through time (tile height as in the forward that wrote the tape)
+  const bool use16 = lstm_use16(c, geom, 2, M);
+  const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;
+  if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
+  {
+    ProfScope ps(c, CAT_LSTM, st);
+    const int rc = use16 ? lstm_bptt16_launch(ntl, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom, LNP)
+                         : lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom,
+                                            LNP);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
+  }
+  if (br.lstm_record && hipEventRecord(br.lstm_record, st) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger record");
+  // 4. LSTM parameter gradients (the LSTM's input is the block input x)
+  for (int d = 0; d < 2; ++d) {
+    const char* sfx = d ? "_reverse" : "";
+    const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
+                      bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
+    hipLaunchKernelGGL(slab_reduce_to2_kernel, dim3(512 / 32), dim3(256), 0, st, LNP + (size_t)d * ntl * 512, ntl, (int64_t)512,
+                       G(bih.c_str()), G(bhh.c_str()), -1);
+    LAUNCH_CHECK(c, "d lstm bias");
+    const ALoadDense xl{x_in, M, N, 32};
+    const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
+    for (int half = 0; half < 2; ++half) {
+      const ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
+      if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
+      if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
+    }
+  }
+  // 5. d_in = d_out (residual) + dP_f W_ih_f + dP_b W_ih_b
+  run.slot = br.slot;
+  for (int d = 0; d < 2; ++d) {
+    if constexpr (N == 128) {
+      ALoadCols al{DG, M, 2 * 512, d * 512, 32};
+      EpiAddMaskStoreT<true, false> ep{d_in, d == 0 ? d_out : d_in, nullptr, M, N, 32, N};
+      if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d], ntiles, 1, al, ep, nullptr, N)) return rc;
+    } else {
+      for (int half = 0; half < 2; ++half) {
+        ALoadCols al{DG, M, 2 * 512, d * 512 + half * 256, BMn};
+        EpiAddMaskStoreT<true, false> ep{d_in, d == 0 && half == 0 ? d_out : d_in, nullptr, M, N, BMn, N};
+        if (int rc = launch_gemm<256, 1, WRn, WCn, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d] + (size_t)half * 256 * N, ntiles_n, 1, al,
+                                                         ep, nullptr, N))
+          return rc;
+      }
+    }
+  }
+  br.slot = run.slot;
+  return DPTNAV_OK;
+}
+
 template <int N>
 int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const float* x_in, const float* d_out,
                       float* d_in, int B, int S, float* tape, const PathTape& tp) {
@@ -1007,6 +1117,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   // (DPTNWavEncDec): the same chain with the generic weight-gradient kernel where a tuned shape does not exist and
   // 64-row x 64-column tiles for the data-gradient GEMMs whose output is N wide
   constexpr int WRn = N == 128 ? 1 : 2, WCn = N == 128 ? 4 : 2, BMn = 32 * WRn;
+  if (c->cfg.arch == 1) return run_path_backward_dprnn<N>(c, br, block, path, x_in, d_out, d_in, B, S, tape, tp);
   const dptnav_config& g = c->cfg;
   const PathWeights& w = c->pw[2 * block + path];
   const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
@@ -1933,7 +2044,6 @@ size_t dptnav_train_bwd_workspace_bytes(dptnav_handle h, int B, int S) {
 int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float* x_in, float* x_out, int B, int S,
                               void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture");
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !x_out || !tape)
     return h->fail(DPTNAV_ERR_INVALID, "train_path_forward: bad argument");
   PathTape tp;
@@ -1954,7 +2064,6 @@ int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float*
 int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float* x_in, const float* d_out, float* d_in,
                                int B, int S, void* tape, size_t tape_bytes, void* bws, size_t bws_bytes, void* stream) {
   if (!h) return DPTNAV_ERR_INVALID;
-  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture");
   if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !d_out || !d_in || !tape || !bws)
     return h->fail(DPTNAV_ERR_INVALID, "train_path_backward: bad argument");
@@ -1973,9 +2082,8 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
 
 // ---- training step, whole model -------------------------------------------------------------------------
 static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, ModelTape* mt, BwdPlan* bp) {
-  if (h->cfg.arch != 0) return h->fail(DPTNAV_ERR_INVALID, "training step: built for the DPTN architecture (DPRNN blocks: inference only)");
-  if (h->cfg.num_features != 128 && !h->opt_ln_tape)
-    return h->fail(DPTNAV_ERR_INVALID, "training step with num_features = %d needs option ln_tape = 1", h->cfg.num_features);
+  if ((h->cfg.num_features != 128 || h->cfg.arch != 0) && !h->opt_ln_tape)
+    return h->fail(DPTNAV_ERR_INVALID, "training step of this configuration needs option ln_tape = 1");
   if (!h->cfg.bidir) return h->fail(DPTNAV_ERR_INVALID, "training step: bidir = False not supported yet");
   if (int rc = make_plan(h, B, T, Tv, pl)) return rc;
   make_model_tape(h, B, pl->L, (int)pl->S, Tv, mt);

@@ -754,6 +754,56 @@ struct EpiBiasLNRes {
   }
 };
 
+// EpiBiasLNRes that also leaves zn / rstd on the training tape (DPRNN blocks; see EpiBiasResLNSave)
+template <int GROUP>
+struct EpiBiasLNResSave {
+  static constexpr bool DIRECT = false;
+  static constexpr bool HAS_FINISH = false;
+  float* out;
+  const float* bias;
+  const float* res;    // [M][ld]
+  const float* gamma;
+  const float* beta;
+  int64_t M;
+  int ld;
+  int bm;
+  float* zn_out;       // [M][ld]
+  float* rstd_out;     // [M]
+  struct Cols { float4 b, ga, be; };
+  DEV Cols cols(int /*colgroup*/, int c4) const {
+    return Cols{*reinterpret_cast<const float4*>(bias + 4 * c4), *reinterpret_cast<const float4*>(gamma + 4 * c4),
+                *reinterpret_cast<const float4*>(beta + 4 * c4)};
+  }
+  DEV float4 prefetch(int tile, int row, int c4) const {
+    const int64_t r = (int64_t)tile * bm + row;
+    return r < M ? *reinterpret_cast<const float4*>(res + r * ld + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  DEV float4 prefetchc(int tile, int row, int c4) const {   // clamped, branch-free (rows beyond M are never stored)
+    const int64_t r0 = (int64_t)tile * bm;
+    const int last = (int)(M - 1 - r0 < bm - 1 ? M - 1 - r0 : bm - 1);   // wave-uniform
+    return *reinterpret_cast<const float4*>(res + r0 * ld + (unsigned)((row < last ? row : last) * ld + 4 * c4));
+  }
+  DEV void row(int tile, int row, int /*colgroup*/, int c4, float4 v, float4 x, const Cols& k) const {
+    const int64_t r0 = (int64_t)tile * bm;
+    v.x += k.b.x; v.y += k.b.y; v.z += k.b.z; v.w += k.b.w;
+    const float s = group_sum<GROUP>((v.x + v.y) + (v.z + v.w));
+    const float mu = s * (1.0f / (4 * GROUP));
+    const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+    const float q = group_sum<GROUP>((dx * dx + dy * dy) + (dz * dz + dw * dw));
+    const float rstd = rsqrtf(q * (1.0f / (4 * GROUP)) + 1e-5f);
+    if (r0 + row >= M) return;
+    const float4 zn = make_float4(dx * rstd, dy * rstd, dz * rstd, dw * rstd);
+    float4 y;
+    y.x = zn.x * k.ga.x + k.be.x + x.x;
+    y.y = zn.y * k.ga.y + k.be.y + x.y;
+    y.z = zn.z * k.ga.z + k.be.z + x.z;
+    y.w = zn.w * k.ga.w + k.be.w + x.w;
+    *reinterpret_cast<float4*>(out + r0 * ld + (unsigned)(row * ld + 4 * c4)) = y;
+    *reinterpret_cast<float4*>(zn_out + r0 * ld + (unsigned)(row * ld + 4 * c4)) = zn;
+    if (c4 == 0) rstd_out[r0 + row] = rstd;
+  }
+};
+
 // LSTM pre-activations straight from the accumulators into the fragment layout (common.h)
 struct EpiLstmPre {
   static constexpr bool DIRECT = true;

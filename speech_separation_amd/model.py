@@ -156,15 +156,14 @@ class _DPTNBase(nn.Module):
         return ppm, seed
 
     def _train_kernels_built(self) -> bool:
-        return self.cfg.arch == "dptn" and self.cfg.num_features in (128, 64) and self.cfg.bidir
+        return self.cfg.num_features in (128, 64) and self.cfg.bidir        # DPTN and DPRNN blocks
 
     def _run(self, mix, e1, e2):
         cont = lambda t: None if t is None else t.contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if not self._train_kernels_built():
-                raise NotImplementedError("the training step (backward kernels) is built for the DPTN architecture with "
-                                          "num_features in {128, 64}, bidir=True (DPTNAVWavEncDec / DPTNWavEncDec); use "
-                                          "torch.no_grad() here")
+                raise NotImplementedError("the training step (backward kernels) is built for num_features in {128, 64} and "
+                                          "bidir=True; use torch.no_grad() here")
             s1, s2 = _SeparateFn.apply(self, mix.contiguous(), cont(e1), cont(e2), *self.parameters())
             return {"s1_pred": s1, "s2_pred": s2}
         eng = self._get_engine(mix.device)

@@ -352,7 +352,8 @@ def test_full_size_training_step_is_deterministic(dev):
 
 
 @pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
-@pytest.mark.parametrize("name,copies", [("grad_mid_av", 1), ("grad_full_av", 1), ("grad_full_av", 16), ("grad_mid_audio", 1)])
+@pytest.mark.parametrize("name,copies", [("grad_mid_av", 1), ("grad_full_av", 1), ("grad_full_av", 16), ("grad_mid_audio", 1),
+                                         ("grad_mid_dprnn", 1)])
 def test_training_step_matches_reference_gradients(dev, golden, name, copies, lstm_tile):
     """BASELINE config 4 against the REFERENCE's own numbers: tests/golden/grad_*.npz hold the loss and d loss / d every
     parameter that the imported reference produced with `model.train(); outputs = model(**batch); SiSNRWavLoss;
@@ -361,7 +362,7 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     loss (dptnav_pit_sisnr_loss); the truth is the same reference step run in fp64.  `copies` = 16 repeats the fixture's one mixture over the batch of config 4
     (B=16 x T=32000, 6 blocks): the batch mean of 16 identical terms is the single term, so loss and gradients must
     reproduce the B=1 reference numbers while every kernel runs at its full BASELINE size (two halves, two streams)."""
-    from speech_separation_amd import DPTNAVWavEncDec, DPTNWavEncDec
+    from speech_separation_amd import DPRNNEncDec, DPTNAVWavEncDec, DPTNWavEncDec
     from speech_separation_amd.spec import synthetic_inputs
     from speech_separation_amd.train import SiSNRWavLoss
     from tests.test_oracle_golden import reference_gradient_report
@@ -372,7 +373,11 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     sd = synthetic_state_dict(cfg, seed=wseed)
     assert weights_digest(sd) == str(z["digest"])
     kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
-    if cfg.audio_only:           # grad_mid_audio: the reference's DPTNWavEncDec (dptn_wav.py:64-126), 64 features
+    if cfg.arch == "dprnn":      # grad_mid_dprnn: the reference's DPRNNEncDec (dprnn.py:230-289)
+        for k in ("video_emb_size", "hidden_video", "num_heads", "dropout"):
+            kw.pop(k)
+        model = DPRNNEncDec(**kw)
+    elif cfg.audio_only:         # grad_mid_audio: the reference's DPTNWavEncDec (dptn_wav.py:64-126), 64 features
         for k in ("video_emb_size", "hidden_video"):
             kw.pop(k)
         model = DPTNWavEncDec(**kw)
@@ -425,3 +430,53 @@ def test_training_rejects_long_video_before_launching_anything(dev):
     s1, s2 = eng.forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
     torch.cuda.synchronize()
     assert torch.isfinite(s1).all() and torch.isfinite(s2).all()
+
+
+@pytest.mark.parametrize("features", [64, 128])
+@pytest.mark.parametrize("path", [0, 1])
+def test_dprnn_path_backward_matches_autograd(dev, path, features):
+    """One DPRNN block half (IntraChunkRNN / InterChunkRNN, dprnn.py:24-47,65-89: bi-LSTM -> fc -> LayerNorm -> + x) with
+    tape + backward against fp64 autograd on the stock composition: d x and the 12 parameter gradients."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import DPRNN_AUDIO
+    cfg = DPTNConfig(**{**DPRNN_AUDIO.to_dict(), "num_blocks": 1, "num_features": features, "hidden_video": features,
+                        "chunk_size": 50, "step_size": 25})
+    sd = synthetic_state_dict(cfg, seed=4)
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(sd, dev))
+    grads = eng.bind_grads()
+    B, S, K, N = 2, 7, cfg.chunk_size, cfg.num_features
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, S, K, N)).astype(np.float32)
+    dy = rng.standard_normal((B, S, K, N)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev)
+    y, tape = eng.train_path_forward(0, path, xt)
+    y_inf = eng.stage_path(0, path, xt)
+    assert O.agreement_db(y.cpu().numpy(), y_inf.cpu().numpy()) > 120
+    dx = eng.train_path_backward(0, path, xt, torch.from_numpy(dy).to(dev), tape)
+    torch.cuda.synchronize()
+
+    ref = StockDPTN(cfg, sd)
+    name = "intra_chunk_block" if path == 0 else "inter_chunk_block"
+    pre = f"dprnn.model.0.{name}."
+    _, _, rnn = ref.paths[path]
+    rnn = rnn.double()
+    params = {k: v.double().requires_grad_(True) for k, v in ref.sd.items() if k.startswith(pre)}
+    ref.sd.update(params)
+    for p in rnn.parameters():
+        p.requires_grad_(True)
+    xs = torch.from_numpy(x).double()
+    seqs = (xs.reshape(B * S, K, N) if path == 0 else xs.transpose(1, 2).reshape(B * K, S, N)).requires_grad_(True)
+    with torch.enable_grad():
+        out = ref._path(seqs, pre, None, rnn)
+        dys = torch.from_numpy(dy).double()
+        out.backward(dys.reshape(B * S, K, N) if path == 0 else dys.transpose(1, 2).reshape(B * K, S, N))
+    want_dx = seqs.grad.reshape(B, S, K, N) if path == 0 else seqs.grad.reshape(B, K, S, N).transpose(1, 2)
+    assert O.agreement_db(dx.cpu().numpy(), want_dx.numpy()) > 80, "d x"
+    want = {"rnn." + k: v.grad for k, v in rnn.named_parameters()}
+    for leaf in ("fc.weight", "fc.bias", "norm1d.weight", "norm1d.bias"):
+        want[leaf] = params[pre + leaf].grad
+    for leaf, gref in want.items():
+        got = grads[pre + leaf].cpu().numpy()
+        assert got.shape == tuple(gref.shape), leaf
+        assert O.agreement_db(got, gref.numpy()) > 70, (leaf, O.agreement_db(got, gref.numpy()))

@@ -163,7 +163,7 @@ def reference_gradient_report(z, grads, floor_db=60.0, margin_db=3.0):
     return fails, worst_db, worst_norm
 
 
-@pytest.mark.parametrize("name", ["grad_tiny_av", "grad_mid_av", "grad_mid_audio"])
+@pytest.mark.parametrize("name", ["grad_tiny_av", "grad_mid_av", "grad_mid_audio", "grad_mid_dprnn"])
 def test_stock_autograd_matches_reference_gradients(golden, name):
     """The gradient oracle of the GPU backward tests (torch.autograd through oracle/torch_stock.py + SiSNRWavLossTorch, in
     fp64) reproduces what the REFERENCE's own training step produced in fp64: loss (ss_losses.py:21-26,96-130) and
@@ -184,9 +184,9 @@ def test_stock_autograd_matches_reference_gradients(golden, name):
         assert O.agreement_db(out32[k].numpy(), z["tap." + k]) > 100
     ref = StockDPTN(cfg, sd)
     ref.sd = {k: v.double().requires_grad_(True) for k, v in ref.sd.items()}
-    ref.paths = [(pre, m.double(), r.double()) for pre, m, r in ref.paths]
+    ref.paths = [(pre, m.double() if m is not None else None, r.double()) for pre, m, r in ref.paths]
     for _, m, r in ref.paths:
-        for p in list(m.parameters()) + list(r.parameters()):
+        for p in (list(m.parameters()) if m is not None else []) + list(r.parameters()):
             p.requires_grad_(True)
     batch = {k: torch.from_numpy(v).double() for k, v in inp.items()}
     with torch.enable_grad():
@@ -196,8 +196,9 @@ def test_stock_autograd_matches_reference_gradients(golden, name):
     assert abs(float(loss.detach()) - float(z["val.loss64"])) < 1e-9 * abs(float(z["val.loss64"]))
     grads = {}
     for pre, m, r in ref.paths:
-        grads[pre + "mha.in_proj_weight"], grads[pre + "mha.in_proj_bias"] = m.in_proj_weight.grad, m.in_proj_bias.grad
-        grads[pre + "mha.out_proj.weight"], grads[pre + "mha.out_proj.bias"] = m.out_proj.weight.grad, m.out_proj.bias.grad
+        if m is not None:
+            grads[pre + "mha.in_proj_weight"], grads[pre + "mha.in_proj_bias"] = m.in_proj_weight.grad, m.in_proj_bias.grad
+            grads[pre + "mha.out_proj.weight"], grads[pre + "mha.out_proj.bias"] = m.out_proj.weight.grad, m.out_proj.bias.grad
         for k, v in r.named_parameters():
             grads[pre + "rnn." + k] = v.grad
     for k, v in ref.sd.items():

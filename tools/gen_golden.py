@@ -170,6 +170,8 @@ def gradient_fixtures(dptn_wav, losses, only):
         ("grad_full_av", DPTNConfig(**{**DPTN_AV.to_dict(), "dropout": 0.0}), dict(B=1, T=32000, Tv=50), 0, 123),
         # the reference's audio-only DPTNWavEncDec (model/dptn_wav.yaml: 64 features), trainable here since round 3
         ("grad_mid_audio", DPTNConfig(**{**DPTN_AUDIO.to_dict(), "num_blocks": 2, "dropout": 0.0}), dict(B=2, T=8000, Tv=50), 0, 123),
+        # the reference's DPRNNEncDec (model/dprnn.yaml: 64 features, kernel 2, chunks of 250)
+        ("grad_mid_dprnn", DPTNConfig(**{**DPRNN_AUDIO.to_dict(), "num_blocks": 2, "dropout": 0.0}), dict(B=2, T=3000, Tv=50), 0, 123),
     ]
     for name, cfg, shp, wseed, iseed in cases:
         if only and name not in only:
