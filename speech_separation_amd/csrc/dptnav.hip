@@ -663,6 +663,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     } else if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (pb.train && pb.zn2) {
+      ALoadDense al{hc, M, LSTM_H, BM};
+      EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
     } else {
       ALoadDense al{hc, M, LSTM_H, BM};
       if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -692,6 +696,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     } else if (w.ndir == 2) {
       ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (pb.train && pb.zn2) {
+      ALoadColsReLU al{hc, M, LSTM_H, 0, BM};
+      EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
+      if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
     } else if (pb.train) {
       ALoadColsReLU al{hc, M, LSTM_H, 0, BM};
       if (int rc = launch_gemm<LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -1017,7 +1025,7 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
   const PathWeights& w = c->pw[2 * block + path];
   const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
   auto G = [&](const char* leaf) { return br.gptr[c->slot(pre + leaf)]; };
-  if (w.ndir != 2) return c->fail(DPTNAV_ERR_INVALID, "training step: unidirectional inter-chunk LSTM not supported yet");
+  const int nd = w.ndir;                 // 2, or 1 for the inter-chunk path of a bidir = False model (dprnn.py:56-63)
   if (!tp.zn2) return c->fail(DPTNAV_ERR_INVALID, "training step of DPRNN blocks needs option ln_tape = 1");
   const int K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K;
@@ -1043,37 +1051,57 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
     LAUNCH_CHECK(c, "norm1d backward");
   }
   // 2. fc gradients, d h = dz W_fc
-  {
-    ALoadCols yl{DZ, M, N, 0, 32};
-    ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32};
-    if constexpr (N == 128) {
-      if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d fc weight + bias", ntiles, yl, xl, G("fc.weight"), G("fc.bias"))) return rc;
-    } else {
-      if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d fc weight", ntiles, yl, xl, G("fc.weight"))) return rc;
-      if (int rc = launch_colsum<N>(c, br, "d fc bias", DZ, M, N, 0, G("fc.bias"))) return rc;
+  if (nd == 1) {
+    {
+      ALoadCols yl{DZ, M, N, 0, 32};
+      ALoadCols xl{hc, M, LSTM_H, 0, 32};
+      if constexpr (N == 128) {
+        if (int rc = launch_wgrad<N, LSTM_H>(c, br, "d fc weight + bias", ntiles, yl, xl, G("fc.weight"), G("fc.bias"))) return rc;
+      } else {
+        if (int rc = launch_wgrad_generic<N, LSTM_H>(c, br, "d fc weight", ntiles, yl, xl, G("fc.weight"))) return rc;
+        if (int rc = launch_colsum<N>(c, br, "d fc bias", DZ, M, N, 0, G("fc.bias"))) return rc;
+      }
     }
+    run.slot = br.slot;
+    {
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, false> ep{DHb, nullptr, nullptr, M, LSTM_H, 32, LSTM_H};
+      if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, LSTM_H)) return rc;
+    }
+    br.slot = run.slot;
+  } else {
+    {
+      ALoadCols yl{DZ, M, N, 0, 32};
+      ALoadCols xl{hc, M, 2 * LSTM_H, 0, 32};
+      if constexpr (N == 128) {
+        if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d fc weight + bias", ntiles, yl, xl, G("fc.weight"), G("fc.bias"))) return rc;
+      } else {
+        if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d fc weight", ntiles, yl, xl, G("fc.weight"))) return rc;
+        if (int rc = launch_colsum<N>(c, br, "d fc bias", DZ, M, N, 0, G("fc.bias"))) return rc;
+      }
+    }
+    run.slot = br.slot;
+    {
+      ALoadDense al{DZ, M, N, 32};
+      EpiAddMaskStoreT<false, false> ep{DHb, nullptr, nullptr, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+      if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H)) return rc;
+    }
+    br.slot = run.slot;
   }
-  run.slot = br.slot;
-  {
-    ALoadDense al{DZ, M, N, 32};
-    EpiAddMaskStoreT<false, false> ep{DHb, nullptr, nullptr, M, 2 * LSTM_H, 32, 2 * LSTM_H};
-    if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H)) return rc;
-  }
-  br.slot = run.slot;
   // 3. LSTM backward through time (tile height as in the forward that wrote the tape)
-  const bool use16 = lstm_use16(c, geom, 2, M);
+  const bool use16 = lstm_use16(c, geom, nd, M);
   const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
   {
     ProfScope ps(c, CAT_LSTM, st);
-    const int rc = use16 ? lstm_bptt16_launch(ntl, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom, LNP)
-                         : lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M, geom,
+    const int rc = use16 ? lstm_bptt16_launch(ntl, nd, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, nd * LSTM_H, DG, nd * 512, (int)M, geom, LNP)
+                         : lstm_bptt_launch(geom.nst, nd, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, nd * LSTM_H, DG, nd * 512, (int)M, geom,
                                             LNP);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
   }
   if (br.lstm_record && hipEventRecord(br.lstm_record, st) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger record");
   // 4. LSTM parameter gradients (the LSTM's input is the block input x)
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < nd; ++d) {
     const char* sfx = d ? "_reverse" : "";
     const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
                       bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
@@ -1081,23 +1109,23 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
                        G(bih.c_str()), G(bhh.c_str()), -1);
     LAUNCH_CHECK(c, "d lstm bias");
     const ALoadDense xl{x_in, M, N, 32};
-    const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
+    const ALoadSeqShift hl = make_seq_shift(hc, M, nd * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
     for (int half = 0; half < 2; ++half) {
-      const ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
+      const ALoadCols yl{DG, M, nd * 512, d * 512 + half * 256, 32};
       if (int rc = launch_wgrad<256, N>(c, br, "d w_ih", ntiles, yl, xl, G(wih.c_str()) + half * 256 * N)) return rc;
       if (int rc = launch_wgrad<256, LSTM_H>(c, br, "d w_hh", ntiles, yl, hl, G(whh.c_str()) + half * 256 * LSTM_H)) return rc;
     }
   }
   // 5. d_in = d_out (residual) + dP_f W_ih_f + dP_b W_ih_b
   run.slot = br.slot;
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      ALoadCols al{DG, M, 2 * 512, d * 512, 32};
+      ALoadCols al{DG, M, nd * 512, d * 512, 32};
       EpiAddMaskStoreT<true, false> ep{d_in, d == 0 ? d_out : d_in, nullptr, M, N, 32, N};
       if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d], ntiles, 1, al, ep, nullptr, N)) return rc;
     } else {
       for (int half = 0; half < 2; ++half) {
-        ALoadCols al{DG, M, 2 * 512, d * 512 + half * 256, BMn};
+        ALoadCols al{DG, M, nd * 512, d * 512 + half * 256, BMn};
         EpiAddMaskStoreT<true, false> ep{d_in, d == 0 && half == 0 ? d_out : d_in, nullptr, M, N, BMn, N};
         if (int rc = launch_gemm<256, 1, WRn, WCn, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d] + (size_t)half * 256 * N, ntiles_n, 1, al,
                                                          ep, nullptr, N))
@@ -1122,7 +1150,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   const PathWeights& w = c->pw[2 * block + path];
   const std::string pre = "dprnn.model." + std::to_string(block) + (path == 0 ? ".intra_chunk_block." : ".inter_chunk_block.");
   auto G = [&](const char* leaf) { return br.gptr[c->slot(pre + leaf)]; };
-  if (w.ndir != 2) return c->fail(DPTNAV_ERR_INVALID, "training step: unidirectional inter-chunk LSTM not supported yet");
+  const int nd = w.ndir;                 // 2, or 1 for the inter-chunk path of a bidir = False model (dptn.py:60)
   const int K = g.chunk_size;
   const int64_t M = (int64_t)B * S * K;
   const SeqGeom geom = make_geom(path, B, S, K);
@@ -1167,52 +1195,72 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   br.slot = run.slot;
   // 2 + 3. ffn parameter gradients and d h = (dz2 W_f) masked by the ReLU.  Option wgrad_ride (default): ONE launch -- the
   //        data-gradient GEMM stages the dz2 tile anyway and forms dW_f / db_f on the side (WgradRider, gemm_ws.h)
-  bool rode = false;
-  if constexpr (N == 128) {
-    if (c->opt_wgrad_ride) {
-      rode = true;
-      run.slot = br.slot;
-      ALoadDense al{DZ, M, N, 32};
-      EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
-      float* slab = br.ws + br.pl.slab;
-      int rgrid = 0;
-      // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
-      WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
-                                                     slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
-      if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
-                                                        2 * LSTM_H, &rgrid, rd))
-        return rc;
-      br.slot = run.slot;
-      if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
-        return rc;
-    }
-  }
-  if (!rode) {
+  if (nd == 1) {   // one direction: W_f is [N][128]; the plain schedule (no rider)
     {
       ALoadCols yl{DZ, M, N, 0, 32};
-      ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
+      ALoadColsReLU xl{hc, M, LSTM_H, 0, 32};
       if constexpr (N == 128) {
-        if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
-          return rc;
+        if (int rc = launch_wgrad<N, LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias"))) return rc;
       } else {
-        if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
+        if (int rc = launch_wgrad_generic<N, LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
         if (int rc = launch_colsum<N>(c, br, "d ffn bias", DZ, M, N, 0, G("ffn.1.bias"))) return rc;
       }
     }
     run.slot = br.slot;
     {
       ALoadDense al{DZ, M, N, 32};
-      EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
-      if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
-        return rc;
+      EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, LSTM_H, 32, LSTM_H};
+      if (int rc = launch_gemm<N, 1, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, LSTM_H)) return rc;
     }
     br.slot = run.slot;
+  } else {
+    bool rode = false;
+    if constexpr (N == 128) {
+      if (c->opt_wgrad_ride) {
+        rode = true;
+        run.slot = br.slot;
+        ALoadDense al{DZ, M, N, 32};
+        EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+        float* slab = br.ws + br.pl.slab;
+        int rgrid = 0;
+        // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
+        WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
+                                                       slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
+        if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
+                                                          2 * LSTM_H, &rgrid, rd))
+          return rc;
+        br.slot = run.slot;
+        if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
+          return rc;
+      }
+    }
+    if (!rode) {
+      {
+        ALoadCols yl{DZ, M, N, 0, 32};
+        ALoadColsReLU xl{hc, M, 2 * LSTM_H, 0, 32};
+        if constexpr (N == 128) {
+          if (int rc = launch_wgrad<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", ntiles, yl, xl, G("ffn.1.weight"), G("ffn.1.bias")))
+            return rc;
+        } else {
+          if (int rc = launch_wgrad_generic<N, 2 * LSTM_H>(c, br, "d ffn weight", ntiles, yl, xl, G("ffn.1.weight"))) return rc;
+          if (int rc = launch_colsum<N>(c, br, "d ffn bias", DZ, M, N, 0, G("ffn.1.bias"))) return rc;
+        }
+      }
+      run.slot = br.slot;
+      {
+        ALoadDense al{DZ, M, N, 32};
+        EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
+        if (int rc = launch_gemm<N, 2, 1, 4, true>(c, run, CAT_FFN, "d h", w.ffn_w, ntiles, 1, al, ep, nullptr, 2 * LSTM_H))
+          return rc;
+      }
+      br.slot = run.slot;
+    }
   }
   // 4. LSTM backward through time (tile height as in the forward that wrote the tape)
-  const bool use16 = lstm_use16(c, geom, 2, M);
+  const bool use16 = lstm_use16(c, geom, nd, M);
   const int ntl = use16 ? (geom.nseq + 15) / 16 : geom.nst;   // workgroups per direction = partial bias rows
   if (br.lstm_wait && hipStreamWaitEvent(st, br.lstm_wait, 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "bptt stagger wait");
-  const bool wg2 = c->opt_wgrad2 && N == LSTM_H;        // wgrad2 pairs two X operands of equal width
+  const bool wg2 = c->opt_wgrad2 && N == LSTM_H && nd == 2;   // wgrad2 pairs two X operands of equal width, four slices
   const bool side = br.side != nullptr && wg2;
   if (side) {   // this path's dP goes to the buffer the weight gradients of two paths ago have (or will have) read
     if (br.dg_sel) DG = br.ws + (br.dg_sel == 1 ? br.pl.dg2 : br.pl.dg3);
@@ -1221,9 +1269,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   {
     ProfScope ps(c, CAT_LSTM, st);
-    const int rc = use16 ? lstm_bptt16_launch(ntl, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M,
+    const int rc = use16 ? lstm_bptt16_launch(ntl, nd, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, nd * LSTM_H, DG, nd * 512, (int)M,
                                               geom, LNP)
-                         : lstm_bptt_launch(geom.nst, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, 2 * LSTM_H, DG, 2 * 512, (int)M,
+                         : lstm_bptt_launch(geom.nst, nd, st, gates, cst, w.w_hh[0], w.w_hh[1], DHb, nd * LSTM_H, DG, nd * 512, (int)M,
                                             geom, LNP);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm bptt: %s", hipGetErrorString((hipError_t)rc));
   }
@@ -1231,7 +1279,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   // 5. LSTM parameter gradients
   Wgrad2Args<ALoadCols, ALoadDense, ALoadSeqShift, 4> wa{};
   float *gA[4], *gB[4];
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < nd; ++d) {
     const char* sfx = d ? "_reverse" : "";
     const std::string wih = std::string("rnn.weight_ih_l0") + sfx, whh = std::string("rnn.weight_hh_l0") + sfx,
                       bih = std::string("rnn.bias_ih_l0") + sfx, bhh = std::string("rnn.bias_hh_l0") + sfx;
@@ -1240,9 +1288,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
                        (int64_t)512, G(bih.c_str()), G(bhh.c_str()), -1);
     LAUNCH_CHECK(c, "d lstm bias");
     const ALoadDense xl{y1, M, N, 32};
-    const ALoadSeqShift hl = make_seq_shift(hc, M, 2 * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
+    const ALoadSeqShift hl = make_seq_shift(hc, M, nd * LSTM_H, d * LSTM_H, 32, d ? -1 : 1, geom);
     for (int half = 0; half < 2; ++half) {   // 512 gate rows as 2 x 256: 16 accumulator tiles per wave would spill
-      const ALoadCols yl{DG, M, 2 * 512, d * 512 + half * 256, 32};
+      const ALoadCols yl{DG, M, nd * 512, d * 512 + half * 256, 32};
       if (wg2) {   // W_ih and W_hh gradients in ONE pass over dP; the four (direction, half) slices in one launch
         if constexpr (N == LSTM_H) {
           const int s4 = 2 * d + half;
@@ -1278,16 +1326,16 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   // 6. d y1 = dz2 (residual) + dG_f W_ih_f + dG_b W_ih_b
   run.slot = br.slot;
-  for (int d = 0; d < 2; ++d) {
+  for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      ALoadCols al{DG, M, 2 * 512, d * 512, 32};
+      ALoadCols al{DG, M, nd * 512, d * 512, 32};
       EpiAddMaskStoreT<true, false> ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
       if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
         return rc;
     } else {
       // 64-row tiles: a 64 x 512 A tile (double buffered) does not fit the LDS, so the gate columns go in two halves
       for (int half = 0; half < 2; ++half) {
-        ALoadCols al{DG, M, 2 * 512, d * 512 + half * 256, BMn};
+        ALoadCols al{DG, M, nd * 512, d * 512 + half * 256, BMn};
         EpiAddMaskStoreT<true, false> ep{DY1, d == 0 && half == 0 ? DZ : DY1, nullptr, M, N, BMn, N};
         if (int rc = launch_gemm<256, 1, WRn, WCn, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d] + (size_t)half * 256 * N, ntiles_n, 1,
                                                          al, ep, nullptr, N))
@@ -2084,7 +2132,6 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
 static int train_shapes(dptnav_handle h, int B, int64_t T, int Tv, Plan* pl, ModelTape* mt, BwdPlan* bp) {
   if ((h->cfg.num_features != 128 || h->cfg.arch != 0) && !h->opt_ln_tape)
     return h->fail(DPTNAV_ERR_INVALID, "training step of this configuration needs option ln_tape = 1");
-  if (!h->cfg.bidir) return h->fail(DPTNAV_ERR_INVALID, "training step: bidir = False not supported yet");
   if (int rc = make_plan(h, B, T, Tv, pl)) return rc;
   make_model_tape(h, B, pl->L, (int)pl->S, Tv, mt);
   make_bwd_plan(h, B, (int)pl->S, bp, pl->L, Tv);

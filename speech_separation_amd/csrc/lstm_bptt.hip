@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(const float* __restrict_
 
 }  // namespace
 
-int lstm_bptt_launch(int nst, void* stream, const float* tape_gates, const float* tape_c, const float* whh_f,
+int lstm_bptt_launch(int nst, int ndir, void* stream, const float* tape_gates, const float* tape_c, const float* whh_f,
                      const float* whh_b, const float* dh_up, int ldh, float* dg_out, int ldg, int dump_row,
                      const SeqGeom& g, float* bias_partials) {
   static PerDeviceOnce ready;
@@ -224,7 +224,7 @@ int lstm_bptt_launch(int nst, void* stream, const float* tape_gates, const float
     if (e != hipSuccess) return (int)e;
     ready.set(dev);
   }
-  hipLaunchKernelGGL(lstm_bptt_kernel, dim3(nst, 2), dim3(256), BPTT_LDS_BYTES, static_cast<hipStream_t>(stream), tape_gates,
+  hipLaunchKernelGGL(lstm_bptt_kernel, dim3(nst, ndir == 1 ? 1 : 2), dim3(256), BPTT_LDS_BYTES, static_cast<hipStream_t>(stream), tape_gates,
                      tape_c, whh_f, whh_b, dh_up, ldh, dg_out, ldg, dump_row, g, bias_partials);
   return (int)hipGetLastError();
 }

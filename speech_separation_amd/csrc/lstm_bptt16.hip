@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void lstm_bptt16_kernel(const float* __restric
 
 }  // namespace
 
-int lstm_bptt16_launch(int nst16, void* stream, const float* tape_gates, const float* tape_c, const float* whh_f,
+int lstm_bptt16_launch(int nst16, int ndir, void* stream, const float* tape_gates, const float* tape_c, const float* whh_f,
                        const float* whh_b, const float* dh_up, int ldh, float* dg_out, int ldg, int dump_row,
                        const SeqGeom& g, float* bias_partials) {
   static PerDeviceOnce ready;
@@ -246,7 +246,7 @@ int lstm_bptt16_launch(int nst16, void* stream, const float* tape_gates, const f
     if (e != hipSuccess) return (int)e;
     ready.set(dev);
   }
-  hipLaunchKernelGGL(lstm_bptt16_kernel, dim3(nst16, 2), dim3(256), BPTT16_LDS_BYTES, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(lstm_bptt16_kernel, dim3(nst16, ndir == 1 ? 1 : 2), dim3(256), BPTT16_LDS_BYTES, static_cast<hipStream_t>(stream),
                      tape_gates, tape_c, whh_f, whh_b, dh_up, ldh, dg_out, ldg, dump_row, g, nst16, bias_partials);
   return (int)hipGetLastError();
 }

@@ -156,14 +156,14 @@ class _DPTNBase(nn.Module):
         return ppm, seed
 
     def _train_kernels_built(self) -> bool:
-        return self.cfg.num_features in (128, 64) and self.cfg.bidir        # DPTN and DPRNN blocks
+        return self.cfg.num_features in (128, 64)        # DPTN and DPRNN blocks, bidirectional or not
 
     def _run(self, mix, e1, e2):
         cont = lambda t: None if t is None else t.contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if not self._train_kernels_built():
-                raise NotImplementedError("the training step (backward kernels) is built for num_features in {128, 64} and "
-                                          "bidir=True; use torch.no_grad() here")
+                raise NotImplementedError("the training step (backward kernels) is built for num_features in {128, 64}; use "
+                                          "torch.no_grad() here")
             s1, s2 = _SeparateFn.apply(self, mix.contiguous(), cont(e1), cont(e2), *self.parameters())
             return {"s1_pred": s1, "s2_pred": s2}
         eng = self._get_engine(mix.device)
@@ -172,8 +172,8 @@ class _DPTNBase(nn.Module):
         # is not built, say so instead of silently returning the eval-mode result.  DPRNN blocks have no dropout.
         if self.training and self.cfg.arch == "dptn" and self.cfg.dropout > 0:
             if not self._train_kernels_built():
-                raise NotImplementedError("train-mode forward (attention dropout) is built for num_features in {128, 64}, "
-                                          "bidir=True only: call model.eval() for inference")
+                raise NotImplementedError("train-mode forward (attention dropout) is built for num_features in {128, 64} "
+                                          "only: call model.eval() for inference")
             self._arm_dropout(eng)
             s1, s2, _tape = eng.train_forward(mix.contiguous(), cont(e1), cont(e2))
             return {"s1_pred": s1, "s2_pred": s2}
