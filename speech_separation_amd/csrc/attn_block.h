@@ -25,7 +25,7 @@ constexpr int ATTN_PACK_FLOATS = ATTN_PACK_IN + ATTN_PACK_OUT + ATTN_PACK_FFN;
 struct AttnPackSrc {
   const float* w_in;   // mha.in_proj_weight [384][128]
   const float* w_o;    // mha.out_proj.weight [128][128]
-  const float* w_f;    // ffn.1.weight [128][256]
+  const float* w_f;    // ffn.1.weight [128][256]; null for a path with one LSTM direction ([128][128]: no prologue there)
 };
 constexpr int ATTN_PACK_MAX_PATHS = 32;        // per launch
 int attn_pack_launch(void* stream, const AttnPackSrc* src, int npaths, float* dst /* [npaths][ATTN_PACK_FLOATS] */);

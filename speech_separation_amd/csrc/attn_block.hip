@@ -821,6 +821,10 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(AttnPackArgs a, float* _
     const int j = (g >> 6) & 3, jt = (g >> 8) & 3, h = g >> 10;
     src = s.w_o + (size_t)(32 * jt + c) * N + h * DH + 8 * j + 4 * hh;
   } else {                                                     // [head][m][lane]
+    if (s.w_f == nullptr) {   // a path whose FFN is not 128 x 256 (unidirectional LSTM: 128 x 128): never used as a prologue
+      *reinterpret_cast<float4*>(dst + (size_t)path * ATTN_PACK_FLOATS + 4 * (size_t)f) = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
     const int g = f - (ATTN_PACK_IN + ATTN_PACK_OUT) / 4;
     const int m = (g >> 6) & 31, h = g >> 11;
     src = s.w_f + (size_t)(32 * h + c) * 256 + 8 * m + 4 * hh;

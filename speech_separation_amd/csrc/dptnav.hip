@@ -504,7 +504,7 @@ static int pack_attn_weights(dptnav_ctx* c, hipStream_t st, int first, int n, fl
   std::vector<AttnPackSrc> src((size_t)n);
   for (int i = 0; i < n; ++i) {
     const PathWeights& w = c->pw[first + i];
-    src[(size_t)i] = AttnPackSrc{w.in_w, w.out_w, w.ffn_w};
+    src[(size_t)i] = AttnPackSrc{w.in_w, w.out_w, w.ndir == 2 ? w.ffn_w : nullptr};   // [128][256] only with both directions
   }
   const int rc = attn_pack_launch(st, src.data(), n, dst);
   if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention weight pack: %s", hipGetErrorString((hipError_t)rc));
