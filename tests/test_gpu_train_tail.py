@@ -240,3 +240,23 @@ def test_audio_only_model_trains_with_the_fused_tail(dev):
     losses = [float(first["loss"])] + [float(s["loss"]) for s in stats]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert all(float(s["grad_norm"]) > 0 for s in stats)
+
+
+def test_dprnn_trains_at_the_reference_clip_length(dev):
+    """DPRNNEncDec with the reference's hyper-parameters (model/dprnn.yaml: 64 features, kernel 2, 6 blocks, chunks of 250)
+    on 2 s @ 16 kHz clips (T = 32000: L = 31999 frames, S = 254 chunks, 63 500 tokens per mixture, 250- and 254-step
+    recurrences on 32-sequence tiles): two whole steps, finite and decreasing loss, every gradient filled."""
+    from speech_separation_amd import DPRNNEncDec
+    from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
+    model = DPRNNEncDec(num_features=64, kernel_size_enc=2, hidden_dim=128, num_blocks=6, chunk_size=250, step_size=125, bidir=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=1).items()})
+    model = model.to(dev).train()
+    opt = FusedAdamW(model.parameters(), lr=1e-3)
+    inp = synthetic_inputs(model.cfg, B=4, T=32000, Tv=50, seed=2)
+    losses = []
+    for _ in range(3):
+        st = train_step(model, {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}, SiSNRWavLoss(), opt, 10.0)
+        losses.append(float(st["loss"]))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    for k, p_ in model.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all() and float(p_.grad.abs().max()) > 0, k
