@@ -251,6 +251,11 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 accumulation: ~2^-17 relative error per product instead of 2^-24, ~5x less matrix time); lstm16s.hip.
  *   "lstm16" (0/1, default 1): use 16-sequence LSTM tiles whenever a launch then still fits the chip in one round
  *                 (half-batch launches): same CU-time, half the serial time of the recurrence.
+ *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a
+ *                 step takes ~1.2 us instead of ~4.3 us, four times the workgroups) for inference launches of at most
+ *                 1.15 rounds of the chip -- bs = 1..3 whole, sub-batches of up to 4 mixtures at 4 s; 2 = wherever
+ *                 the 16-tile layout is in use (experiments, tests); 0 = never.  Same results to fp32 rounding (the k
+ *                 order of the recurrent sum differs: ~135 dB between the two kernels' forwards).
  *   "inject_fail" (n > 0): fault injection for the error-path tests -- the n-th GEMM-engine launch from now on returns
  *                 DPTNAV_ERR_INVALID (once); the forked entry points must still join their internal streams.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:

@@ -79,6 +79,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
@@ -597,6 +598,14 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const int nst16 = (geom.nseq + 15) / 16;
   const bool use16 = lstm_use16(c, geom, w.ndir, M);
   const bool split = c->opt_split_bf16 && !pb.train;
+  // low-latency recurrence on 4-sequence tiles (reads PRE16): small launches, where 16-sequence tiles leave the chip idle.
+  // A step of 4 sequences takes ~1.25 us against ~4.3 us for 16 (alone on the chip, bs = 1: 0.19 ms per launch instead of
+  // 0.64 ms), so up to a little over one round of the chip it is the shorter launch AND the smaller CU-time.  Measured
+  // (profiles/r03_lstm4_sweep.txt): faster for sub-batches of up to 4 mixtures at 4 s (1.1 rounds; B = 8: 18.0 -> 16.3 ms),
+  // slower inside the B = 16 forward when its 5-mixture sub-batches (1.38 rounds) take it (30.5 -> 31.1 ms).
+  const int nst4 = (geom.nseq + 3) / 4;
+  const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
+                    (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= 23 * c->num_cus));
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   {
     ALoadSeqTile al{lstm_in, N, geom};
@@ -624,6 +633,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     ProfScope ps(c, CAT_LSTM, st);
     const int rc = lstm16s_launch(c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16s: %s", hipGetErrorString((hipError_t)rc));
+  } else if (use4) {
+    ProfScope ps(c, CAT_LSTM, st);
+    const int rc = lstm4_launch(c->cfg.arch == 0, nst4, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
+                                w.ndir * LSTM_H, (int)M, geom);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm4: %s", hipGetErrorString((hipError_t)rc));
   } else if (use16) {
     // lstm_stamps: diagnostic builds; lstm_diag > 0 are timing-only ablations (wrong results), see lstm16.hip
     const int variant = pb.train ? L16_VARIANT_TRAIN : (c->opt_lstm_stamps ? 1 + c->opt_lstm_diag : 0);
@@ -2406,6 +2420,10 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
+  else if (k == "lstm4") {
+    if (value < 0 || value > 2) return h->fail(DPTNAV_ERR_INVALID, "lstm4: 0, 1 or 2");
+    h->opt_lstm4 = (int)value;
+  }
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;

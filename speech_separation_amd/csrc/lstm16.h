@@ -46,3 +46,9 @@ int lstm16s_launch(bool relu, int nst16, int ndir, void* stream, const float* pr
 // ... and of the 32-sequence-tile recurrence (same file; PRE layout of lstm.h).
 int lstm32s_launch(bool relu, int nst, int ndir, void* stream, const float* pre, const float* whh_f, const float* whh_b, float* hc,
                    int ldh, int dump_row, const SeqGeom& g);
+
+// LOW-LATENCY variant on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32): reads the PRE16 layout above as it
+// stands (nst16 = its tile count), one workgroup per direction and 4 sequences, nst4 = ceil(sequences / 4).  Inference
+// only.
+int lstm4_launch(bool relu, int nst4, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
+                 const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g);

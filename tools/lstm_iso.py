@@ -19,10 +19,11 @@ eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
 T = 32000
 S = eng.chunks(T)
 eng.profile(True)
-for B in (8, 16):
+for B in (1, 2, 4, 8, 16):
     x = torch.randn(B, S, cfg.chunk_size, cfg.num_features, device=dev)
-    for tile in (16, 32):
-        eng.set_option("lstm16", 1 if tile == 16 else 0)
+    for tile in (4, 16, 32):
+        eng.set_option("lstm16", 0 if tile == 32 else 1)
+        eng.set_option("lstm4", 2 if tile == 4 else 0)
         for path, name in ((0, "intra"), (1, "inter")):
             eng.stage_path(0, path, x)
             eng.profile_reset()

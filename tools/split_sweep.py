@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: forward time over (batch, sub-batches, recurrence launches in flight) for the two DPTN configurations -- the
-data behind forward_split's rule (options sub_batches / lstm_inflight).   python3 tools/split_sweep.py"""
+data behind forward_split's rule (options sub_batches / lstm_inflight).   python3 tools/split_sweep.py [lstm4 [B ...]]
+(lstm4: 0 / 1 / 2 = the 4-sequence recurrence never / where one round fits / wherever the 16-tile layout is in use)"""
 import os
 import sys
 
@@ -12,14 +13,18 @@ from speech_separation_amd.engine import DptnEngine, params_to_device  # noqa: E
 from speech_separation_amd.spec import DPTN_AUDIO, DPTN_AV, synthetic_inputs, synthetic_state_dict  # noqa: E402
 
 dev = torch.device("cuda:0")
+LSTM4 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+BATCHES = [int(a) for a in sys.argv[2:]] or [4, 8, 12, 16, 20, 24, 32]
+print(f"lstm4 = {LSTM4}")
 for name, cfg in (("dptn_av", DPTN_AV), ("dptn_audio", DPTN_AUDIO)):
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
-    for B in (4, 8, 12, 16, 20, 24, 32):
+    eng.set_option("lstm4", LSTM4)
+    for B in BATCHES:
         inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=32000, Tv=50, seed=0).items()}
         args = (inp["mix"], inp.get("s1_embedding"), inp.get("s2_embedding"))
         res = []
-        for nsub, depth in ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (3, 3), (4, 2), (4, 4)):
+        for nsub, depth in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0)):
             if nsub > B:
                 continue
             eng.set_option("sub_batches", nsub)
