@@ -104,7 +104,7 @@ def stock_gradients(cfg, sd, inp, d1, d2):
     return want
 
 
-@pytest.mark.parametrize("seed", range(100, 116))
+@pytest.mark.parametrize("seed", range(100, 112))
 def test_random_configuration_gradients_match_autograd(seed):
     """The training step's backward (dptnav_train_forward / dptnav_train_backward) for random configurations: every
     parameter gradient against fp64 autograd, both recurrence / BPTT tile heights."""
