@@ -595,6 +595,7 @@ def main():
                                               "a launch's duration (and `frac`) reflects its SHARE of the CUs; `isolated` = the same "
                                               "kernels with nothing else on the chip (whole batch, one stream)",
                          "isolated": iso,
+                         "frac_isolated": next((r["frac"] for r in (iso or []) if r["class"] == dom["class"]), None),
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},
