@@ -24,7 +24,7 @@ for name, cfg in (("dptn_av", DPTN_AV), ("dptn_audio", DPTN_AUDIO)):
         inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=32000, Tv=50, seed=0).items()}
         args = (inp["mix"], inp.get("s1_embedding"), inp.get("s2_embedding"))
         res = []
-        for nsub, depth in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0)):
+        for nsub, depth in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (8, 0)):
             if nsub > B:
                 continue
             eng.set_option("sub_batches", nsub)
