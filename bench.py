@@ -396,7 +396,19 @@ def latency_leg(dev, calls: int = 10):
     res = {"what": "profiler.py protocol (bs = 1, T = 32000): one DPTN-AV forward, synchronised per call", "calls": calls,
            "mean_ms": round(float(np.mean(times)), 3), "std_ms": round(float(np.std(times)), 3), "min_ms": round(min(times), 3),
            "serial_lstm_steps": 6 * (cfg.chunk_size + eng.chunks(T)),
+           "recurrence": "lstm4.hip (4-sequence tiles, v_mfma_f32_4x4x1_16B_f32) for launches of up to 1.15 rounds of the chip",
            "reference_published": "0.09989 s mean / 0.04486 s std on a Kaggle P100, lip-reader included, no device sync (README.md:116-117)"}
+    # the same on 16-sequence tiles (option lstm4 = 0), and small batches (synchronised call time, mean of `calls`)
+    eng.set_option("lstm4", 0)
+    res["mean_ms_16_sequence_tiles"] = round(float(np.mean(timed(lambda: eng.forward(mix, e1, e2, out=out)))), 3)
+    eng.set_option("lstm4", 1)
+    small = {}
+    for b in (2, 4, 8):
+        inp_b = synthetic_inputs(cfg, B=b, T=T, Tv=50, seed=123)
+        mb, e1b, e2b = (torch.from_numpy(inp_b[k]).to(dev) for k in ("mix", "s1_embedding", "s2_embedding"))
+        ob = (torch.empty_like(mb), torch.empty_like(mb))
+        small[f"B={b}"] = round(float(np.mean(timed(lambda: eng.forward(mb, e1b, e2b, out=ob)))), 3)
+    res["small_batches_ms"] = small
     del eng, out
     torch.cuda.empty_cache()
     return res
