@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -42,6 +43,7 @@ from speech_separation_amd.parallel import DistEnv  # noqa: E402
 from speech_separation_amd.spec import (DPRNN_AV, DPTN_AUDIO, DPTN_AV, synthetic_inputs,  # noqa: E402
                                         synthetic_state_dict)
 
+DDP_LEG_LIMIT_S = 240          # N > 1: the optional data-parallel training leg is abandoned after this (the headline is printed anyway)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 256 FLOP/clk x 2.4 GHz
 T_SAMPLES = 32000              # "4 s @ 8 kHz"
 BATCH_PER_GPU = 16
@@ -152,33 +154,62 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12):
-    """BASELINE configs[3] next to the headline (N=1): a few optimizer steps of the same model at batch 16 -- forward with
+def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
+    """BASELINE configs[3] next to the headline: a few optimizer steps of the same model at batch 16 per GPU -- forward with
     tape, device PIT SI-SNR loss, HIP backward, device clip + AdamW, attention dropout 0.1 -- so that the driver-run line
-    carries a training-step figure too (`--config dptn_av_train` is the full-length measurement)."""
+    carries a training-step figure too (`--config dptn_av_train` is the full-length measurement).  With N > 1 ranks EVERY
+    rank calls this (collectives inside): each step all-reduces the 17.8 MB flat gradient over RCCL (train.py), the time
+    is the maximum over ranks and `value` the whole job's mixtures/s.  A rank that cannot set the leg up says so in a
+    handshake BEFORE the first collective of a step, and all ranks skip the leg together."""
     from speech_separation_amd import DPTNAVWavEncDec
     from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step
-    kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
-    model = DPTNAVWavEncDec(**kw)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
-    model = model.to(dev).train()
-    opt = FusedAdamW(model.parameters(), lr=1e-3)
-    batch0 = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123).items()}
-    crit = SiSNRWavLoss()
+    world = env.world if env is not None else 1
+    ready, err = 1.0, None
+    try:
+        kw = {k: v for k, v in cfg.to_dict().items() if k not in ("audio_only", "arch")}
+        model = DPTNAVWavEncDec(**kw)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+        model = model.to(dev).train()
+        opt = FusedAdamW(model.parameters(), lr=1e-3)
+        seed = 123 + (env.rank if env is not None else 0)
+        batch0 = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=seed).items()}
+        crit = SiSNRWavLoss()
+        train_step(model, dict(batch0), crit, opt, 10.0)          # one local step (no collective): allocations, first launches
+        torch.cuda.synchronize(dev)
+    except Exception as e:      # noqa: BLE001
+        ready, err = 0.0, e
+    if world > 1 and env.sum_over_ranks([ready])[0] < world:
+        raise RuntimeError(f"training leg skipped on all ranks: set-up failed on at least one ({err!r} here)")
+    if err is not None:
+        raise err
+    ekw = {"env": env} if world > 1 else {}
     for _ in range(warmup):
-        train_step(model, dict(batch0), crit, opt, 10.0)
+        train_step(model, dict(batch0), crit, opt, 10.0, **ekw)
     torch.cuda.synchronize(dev)
+    if world > 1:
+        env.barrier()
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        stats = train_step(model, dict(batch0), crit, opt, 10.0)
+        stats = train_step(model, dict(batch0), crit, opt, 10.0, **ekw)
     torch.cuda.synchronize(dev)
-    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        env.barrier()
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = env.max_over_ranks(dt)
+    dt /= steps
     flops = 3.0 * model._engine.flops_per_mixture(T) * B
-    return {"workload": f"configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), batch={B}, T={T}, dropout 0.1",
-            "value": round(B / dt, 3), "unit": "mixtures/sec", "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
-            "frac": round(flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            "note": "frac = 3 x forward FLOPs (612 GFLOP per mixture) / time / fp32-MFMA peak; no host synchronisation in the step",
-            "last_loss": round(float(stats["loss"]), 4)}
+    res = {"workload": f"configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), batch={B} per GPU, T={T}, dropout 0.1",
+           "value": round(world * B / dt, 3), "unit": "mixtures/sec", "n_gpus": world, "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+           "warmup": warmup, "frac": round(flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+           "parallelism": f"dp{world}" + (" (one flat 17.8 MB gradient all-reduce per step over RCCL, then clip + AdamW on every rank)" if world > 1 else ""),
+           "note": "frac = 3 x forward FLOPs (612 GFLOP per mixture) / time / fp32-MFMA peak, per GPU; no host synchronisation in the step",
+           "last_loss": round(float(stats["loss"]), 4)}
+    del model, opt, batch0
+    torch.cuda.empty_cache()
+    return res
 
 
 def bench_train(args, env, cfg, B, T, workload):
@@ -494,8 +525,11 @@ def main():
     headline = args.config == "dptn_av" and not args.pmc_run and env.world == 1 and not args.batch
     if args.config != "dptn_av" or args.pmc_run:
         args.no_cpu_baseline = True     # the CPU leg is only defined for the headline configuration
+    ddp_leg = args.config == "dptn_av" and not args.pmc_run and env.world > 1    # N > 1: data-parallel training leg on all ranks
     if not headline:
-        args.no_train_step = args.no_other_configs = True
+        args.no_other_configs = True
+        if not ddp_leg:
+            args.no_train_step = True
     if args.config.endswith("_train"):
         return bench_train(args, env, cfg, B, T, workload)
 
@@ -618,15 +652,32 @@ def main():
             "backend": env.backend, "rccl_ranks": env.backend_world() if env.backend == "nccl" else 0,
             "per_rank_mixtures_per_sec": [round(B * args.steps / t, 3) for t in per_rank_s],
         }
-        del eng, out, mix, e1, e2
-        torch.cuda.empty_cache()
-        if not args.no_other_configs:
+    del eng, out, mix, e1, e2
+    torch.cuda.empty_cache()
+    # N > 1: the training leg is data parallel -- every rank runs it (one RCCL all-reduce of the flat gradient per step)
+    ddp_train = None
+    if env.world > 1 and not args.no_train_step:
+        # the headline is measured; a collective that never returns in this optional leg must not cost it: after
+        # DDP_LEG_LIMIT_S rank 0 prints the line without the leg and every rank leaves
+        def give_up():
+            if env.rank == 0:
+                line["train_step"] = {"error": f"data-parallel training leg did not finish within {DDP_LEG_LIMIT_S} s; abandoned"}
+                print(json.dumps(line), flush=True)
+            log(f"rank {env.rank}: training leg abandoned after {DDP_LEG_LIMIT_S} s")
+            os._exit(0)
+        guard = threading.Timer(DDP_LEG_LIMIT_S, give_up)
+        guard.daemon = True
+        guard.start()
+        ddp_train = optional_leg("train_step", train_step_leg, cfg, dev, T, B=B, env=env)
+        guard.cancel()
+    if env.rank == 0:
+        if env.world == 1 and not args.no_other_configs:      # per-GPU figures: the N = 1 line carries them
             line["other_configs"] = {
                 "dptn_audio": optional_leg("other_configs.dptn_audio", forward_leg, "dptn_audio", dev, steps=10, warmup=3, psteps=3),
                 "dprnn_av": optional_leg("other_configs.dprnn_av", forward_leg, "dprnn_av", dev, steps=3, warmup=1, psteps=1)}
             line["latency_b1"] = optional_leg("latency_b1", latency_leg, dev)
         if not args.no_train_step:
-            line["train_step"] = optional_leg("train_step", train_step_leg, cfg, dev, T)
+            line["train_step"] = ddp_train if env.world > 1 else optional_leg("train_step", train_step_leg, cfg, dev, T)
         if env.world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = optional_leg("cpu_baseline", cpu_baseline, cfg, sd)
             if "value" in line["cpu_baseline"]:

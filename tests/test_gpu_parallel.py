@@ -99,6 +99,13 @@ def test_bench_launches_its_own_ranks(config):
     assert np.isfinite(line["value"]) and line["value"] > 0
     # whole-job throughput counts both ranks' mixtures
     assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
+    if config == "dptn_av":
+        # the forward line of an N > 1 launch carries a DATA-PARALLEL training leg: every rank steps, one gradient
+        # all-reduce per step (here over gloo), whole-job mixtures/s
+        tr = line["train_step"]
+        assert "error" not in tr, tr
+        assert tr["n_gpus"] == 2 and tr["parallelism"].startswith("dp2") and tr["value"] > 0 and np.isfinite(tr["last_loss"])
+        assert abs(tr["value"] - 2 * 2 / (tr["ms_per_step"] / 1e3)) < 1e-2 * tr["value"]
 
 
 def _rccl_worker(port, q):
