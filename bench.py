@@ -18,7 +18,11 @@ Rank 0 prints ONE JSON line: the contract fields plus
                      recurrence, pre-activation GEMM, ...), so the line is self-consistent with profiles/*kernel_stats.csv,
   "other_configs" -- short legs of BASELINE configs[1] (DPTN audio-only) and configs[4] (DPRNN-AV, B=32 x 8 s) and
   "train_step"    -- of configs[3], appended to the N=1 headline run (each in a try/except: a failing optional leg is
-                     recorded as {"error": ...} and never costs the headline number),
+                     recorded as {"error": ...} and never costs the headline number).  With N > 1 ranks "train_step" is the
+                     DATA-PARALLEL step of configs[3]: every rank runs it on its own 16 mixtures, one flat 17.8 MB gradient
+                     all-reduce per step over RCCL, time = max over ranks, value = whole-job mixtures/s (a watchdog
+                     prints the line without it if a collective never returns); "other_configs" / "latency_b1" are
+                     per-GPU figures and stay with the N=1 line,
   "cpu_baseline"  -- oracle/torch_stock.py (stock PyTorch CPU operators = what the reference runs on CPU)
                      timed on this box's host cores on a bounded sample (rank 0, N=1 only),
   "kernels_ms_per_step" -- device ms per forward by kernel class (same HIP-event measurement).
