@@ -338,10 +338,13 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
             # (against the whole chip's peak) the share of the chip the launch can use at all
             b_launch = B * 2 * cfg.num_blocks / lps
             fits16 = all(-(-int(b_launch * n_) // 16) * d <= n_cus for n_, d in ((S, 2), (K, ndir)))
-            tile = 16 if fits16 else 32
+            # ... and 4-sequence tiles (lstm4.hip, the low-latency kernel) while those are at most 1.15 rounds of the chip
+            fits4 = fits16 and all(20 * (-(-int(b_launch * n_) // 4)) * d <= 23 * n_cus for n_, d in ((S, 2), (K, ndir)))
+            tile = 4 if fits4 else (16 if fits16 else 32)
             wgs = sum(-(-int(b_launch * n_) // tile) * d for n_, d in ((S, 2), (K, ndir))) / 2.0     # mean of intra / inter
             occ = min(float(n_cus), wgs)
-            row.update(kernel="lstm16_kernel" if fits16 else "lstm_recurrence_kernel", pmc_match="lstm16_kernel" if fits16 else "lstm_recurrence_kernel",
+            kname = "lstm4_kernel" if fits4 else ("lstm16_kernel" if fits16 else "lstm_recurrence_kernel")
+            row.update(kernel=kname, pmc_match=kname,
                        workgroups_per_launch=round(wgs, 1), cus_occupied=round(occ, 1), rounds=round(wgs / n_cus, 2),
                        frac_of_occupied_cus=round(tf / (PEAK_F32_MFMA_TFLOPS * occ / n_cus), 4),
                        algorithmic_bytes=int(B * S * K * 2 * cfg.num_blocks / lps) * (4 * cfg.hidden_dim * ndir + cfg.hidden_dim * ndir) * 4)
