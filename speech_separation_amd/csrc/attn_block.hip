@@ -476,8 +476,17 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
     };
     static_for<NKB>(softmax_step);
     __builtin_amdgcn_sched_barrier(0);
+    // PV of the LAST key block: MFMA steps 4g..4g+3 contract keys 8g..8g+7 of the block (ROW32), and the keys past the
+    // sequence's end have p = 0 exactly -- their steps are skipped (wave-uniform; adds of +0, so the result is the same
+    // bit for bit): 8 of 16 steps at 141 positions, 4 of 16 at 150
+    const int last_groups = (len - 32 * (NKB - 1) + 7) >> 3;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o = mfma32(vv[NKB - 1][r], pprev[r], o);
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (g4 < last_groups) {
+#pragma unroll
+        for (int r = 4 * g4; r < 4 * g4 + 4; ++r) o = mfma32(vv[NKB - 1][r], pprev[r], o);
+      }
+    }
     {
       const float inv = fast_rcp(lrun);
 #pragma unroll
