@@ -150,10 +150,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   float4 csum[NCS];
 #pragma unroll
   for (int k = 0; k < NCS; ++k) csum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  TileTickets tickets{queue, (int)blockIdx.x, (int)gridDim.x};
   int ticket_ahead = 0;
   if (tid == 0) {
-    s_next[0] = (int)atomicAdd(queue, 1u);
-    ticket_ahead = (int)atomicAdd(queue, 1u);
+    s_next[0] = tickets.take();
+    ticket_ahead = tickets.take();
   }
   __syncthreads();
   int tile = s_next[0];
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
     const int nf = next < ntiles ? next : ntiles - 1;
-    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
+    if (tid == 0) ticket_ahead = tickets.take();
     // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
     float a[2][Sh::RB], b[2][Sh::CB];
     auto frag = [&](int s, float* fa, float* fb) {
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
   const YLoad yl = args.yl[sl];
   const XLoadA xa = args.xa[sl];
   const XLoadB xb = args.xb[sl];
-  unsigned* queue = queue_base + sl;
+  unsigned* queue = queue_base ? queue_base + sl : nullptr;
   float* slab = slab_base + (size_t)sl * (gridDim.x / NSL) * (2 * NN * KK);
   const int wg = blockIdx.x / NSL;
   using Sh = WgradShape<NN, KK>;
@@ -358,10 +359,11 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
   constexpr int Y4 = NN / 4, X4 = KK / 4;
   constexpr int NY = (32 * Y4) / 256, NX = (32 * X4) / 256;
   float4 py[NY], pxa[NX], pxb[NX];
+  TileTickets tickets{queue, wg, (int)gridDim.x / NSL};
   int ticket_ahead = 0;
   if (tid == 0) {
-    s_next[0] = (int)atomicAdd(queue, 1u);
-    ticket_ahead = (int)atomicAdd(queue, 1u);
+    s_next[0] = tickets.take();
+    ticket_ahead = tickets.take();
   }
   __syncthreads();
   int tile = s_next[0];
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
     __syncthreads();
     const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
     const int nf = next < ntiles ? next : ntiles - 1;
-    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
+    if (tid == 0) ticket_ahead = tickets.take();
     float a[2][Sh::RB], ba[2][Sh::CB], bb[2][Sh::CB];
     auto frag = [&](int s, float* fa, float* fba, float* fbb) {
       const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;

@@ -174,6 +174,22 @@ DEV int64_t pre_tile_offset(int d, int st, int t, int nst, int len) {
 }
 
 
+// Tile tickets of the token-tile kernels (GEMM engine, weight-gradient kernels).  Default: a device-wide counter (zeroed by
+// the host), so a workgroup that starts late -- the kernel shares the chip with another stream's -- simply finds fewer
+// tiles left.  With queue == nullptr (option "deterministic") the static sequence first, first + stride, ...: WHICH
+// workgroup sums WHICH tiles is then fixed, and so is the rounding of every token reduction (bias / weight gradients).
+// Used by thread 0 only; `queue` is wave-uniform (a kernel argument), so the branch is scalar.
+struct TileTickets {
+  unsigned* queue;
+  int next, stride;
+  DEV int take() {
+    if (queue) return (int)atomicAdd(queue, 1u);
+    const int t = next;
+    next += stride;
+    return t;
+  }
+};
+
 // Host helper: "done once per HIP device" flags for function attributes (hipFuncSetAttribute applies to the device
 // that is current; a process may drive several GPUs through several engines).  Up to 64 devices.
 // Atomic: two engines may be driven from two host threads (each handle is single-threaded, the statics are shared);

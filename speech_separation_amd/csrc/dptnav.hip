@@ -79,6 +79,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  bool opt_deterministic = false;   // 1: static tile assignment instead of device-wide tickets (TileTickets): bit-reproducible gradients
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
@@ -457,8 +458,9 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
   if (gx < 1) gx = 1;
   ProfScope ps(c, cat, st);
   if (grid_used) *grid_used = cap_grid(ntiles, gx);
+  unsigned* const queue = run.take_queue(colgroups);
   hipLaunchKernelGGL(kern, dim3(cap_grid(ntiles, gx), colgroups), dim3(256), lds, st, W, Walt, ldw, (int)ntiles,
-                     run.take_queue(colgroups), al, ep, rider);
+                     c->opt_deterministic ? nullptr : queue, al, ep, rider);
   LAUNCH_CHECK(c, what);
   return DPTNAV_OK;
 }
@@ -922,7 +924,8 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
       if (int rc = set_lds(c, kern, lds, what)) return rc;
       ready.set(c->device_id);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab, colslab);
+    unsigned* const queue = br.take_queue(1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, c->opt_deterministic ? nullptr : queue, yl, xl, slab, colslab);
   } else {
     auto kern = wgrad_kernel<NN, KK, YL, XL, false>;
     static PerDeviceOnce ready;
@@ -930,7 +933,8 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
       if (int rc = set_lds(c, kern, lds, what)) return rc;
       ready.set(c->device_id);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, br.take_queue(1), yl, xl, slab, (float*)nullptr);
+    unsigned* const queue = br.take_queue(1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, c->opt_deterministic ? nullptr : queue, yl, xl, slab, (float*)nullptr);
   }
   LAUNCH_CHECK(c, what);
   constexpr int64_t count = (int64_t)NN * KK;
@@ -997,7 +1001,7 @@ int launch_wgrad2(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, c
     if (int rc = set_lds(c, kern, lds, what)) return rc;
     ready.set(c->device_id);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, wst, (int)ntiles, queue, args, slab);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, wst, (int)ntiles, c->opt_deterministic ? nullptr : queue, args, slab);
   LAUNCH_CHECK(c, what);
   constexpr int64_t count = (int64_t)NN * KK;
   FragOuts outs{};
@@ -2419,6 +2423,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_ppm" && value >= 0 && value < 1000000) h->opt_dropout_ppm = value;
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
+  else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {
     if (value < 0 || value > 2) return h->fail(DPTNAV_ERR_INVALID, "lstm4: 0, 1 or 2");

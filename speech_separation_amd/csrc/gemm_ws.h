@@ -279,11 +279,11 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     for (int nt = 0; nt < NT; ++nt) dconst[nt] = epi.direct_const(colgroup, wc * NT + nt, c);
   }
 
-  unsigned* queue = tile_queue + colgroup;
+  TileTickets tickets{tile_queue ? tile_queue + colgroup : nullptr, (int)blockIdx.x, (int)gridDim.x};
   int ticket_ahead = 0;
   if (tid == 0) {
-    s_next[0] = (int)atomicAdd(queue, 1u);
-    ticket_ahead = (int)atomicAdd(queue, 1u);
+    s_next[0] = tickets.take();
+    ticket_ahead = tickets.take();
   }
   __syncthreads();
   float4 pf[NLD];
@@ -377,7 +377,14 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     // request the ticket after the next one HERE, in front of the MFMA block: issued at the loop top it was the youngest
     // memory operation when the A-tile registers are waited for (s_waitcnt vmcnt(0)), i.e. wave 0 sat out the atomic's
     // round trip every tile and the other waves waited for it at the barrier (~1 k cycles per tile)
-    if (tid == 0) ticket_ahead = (int)atomicAdd(queue, 1u);
+    if (tid == 0) ticket_ahead = tickets.take();
+    // The ticket must stay in a VGPR until it is published at the top of the next iteration.  These kernels fill the
+    // register file, and where the allocator parked `ticket_ahead` in an AGPR (a register spill) it had to wait for the
+    // atomic's result RIGHT HERE to copy it over -- s_waitcnt vmcnt(0) behind the A-tile prefetch, i.e. the prefetch's HBM
+    // latency plus the atomic's round trip exposed on every tile (the K4 pre-activation GEMM: 0.79 -> 0.72 ms per launch
+    // alone on the chip once it was gone).  TICKET_KEEP marks a use inside the MFMA block, which makes spilling it
+    // expensive for the allocator; tools/ticket_waits.py checks the generated code of every instantiation.
+#define TICKET_KEEP asm volatile("" ::"v"(ticket_ahead))
     GEMM_STAMP(2);
     // ---- A fragments + MFMA --------------------------------------------------------------------
     f32x16 acc[NT];
@@ -399,6 +406,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
           acc[nt] = mfma32_bf16(ah[m], whi[nt][m], acc[nt]);
           acc[nt] = mfma32_bf16(ah[m], wlo[nt][m], acc[nt]);
           acc[nt] = mfma32_bf16(al[m], whi[nt][m], acc[nt]);
+          TICKET_KEEP;
         }
     } else {
       // fragments are fetched in batches of 16 x ds_read_b128 BEFORE the MFMAs that use them: a read placed
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int m = 0; m < BATCH; ++m) {
+          TICKET_KEEP;
           const float av[4] = {afr[m].x, afr[m].y, afr[m].z, afr[m].w};
 #pragma unroll
           for (int tt = 0; tt < 4; ++tt) {
@@ -504,6 +513,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
       }
     }
     GEMM_STAMP(5);
+    TICKET_KEEP;
+#undef TICKET_KEEP
     tile = next;
     buf ^= 1;
   }

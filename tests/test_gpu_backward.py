@@ -311,11 +311,13 @@ def test_weight_gradient_schedules_agree(dev):
         assert worst[0] > 90, (name, worst)
 
 
-def test_full_size_training_step_is_deterministic(dev):
+@pytest.mark.parametrize("deterministic", [0, 1])
+def test_full_size_training_step_is_deterministic(dev, deterministic):
     """B=16, T=32000 (BASELINE config 4, dropout 0.1): two forward/backward passes with the same dropout seed give
     bit-identical outputs; the parameter gradients agree to fp32 summation order (the token reductions hand their tiles
     out by dynamic tickets, so WHICH workgroup sums which tiles -- not the values summed -- varies from run to run; no
-    float atomics anywhere), and everything is finite."""
+    float atomics anywhere), and everything is finite.  With option deterministic = 1 (static tile order) the gradients
+    are bit-identical too, and equal to the default's up to that summation order."""
     from speech_separation_amd.engine import DptnEngine, params_to_device
     from speech_separation_amd.spec import synthetic_inputs
     cfg = DPTN_AV
@@ -324,6 +326,7 @@ def test_full_size_training_step_is_deterministic(dev):
     grads = eng.bind_grads()
     eng.set_option("dropout_ppm", 100000)
     eng.set_option("dropout_seed", 2024)
+    eng.set_option("deterministic", deterministic)
     B, T = 16, 32000
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=3)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
@@ -338,6 +341,15 @@ def test_full_size_training_step_is_deterministic(dev):
         runs.append((s1.clone(), s2.clone(), eng._grads_flat.clone()))
         del tape
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    if deterministic:
+        assert torch.equal(runs[0][2], runs[1][2]), "static tile order: the gradients must be bit-identical run to run"
+        eng.set_option("deterministic", 0)          # ... and the ticket-driven default computes the same sums in another order
+        s1, s2, tape = eng.train_forward(t["mix"], t["s1_embedding"], t["s2_embedding"])
+        eng.train_backward(t["mix"], t["s1_embedding"], t["s2_embedding"], d1, d2, tape)
+        torch.cuda.synchronize()
+        assert torch.equal(s1, runs[0][0])
+        runs[1] = (s1.clone(), s2.clone(), eng._grads_flat.clone())
+        del tape
     ga, gb = runs[0][2].double(), runs[1][2].double()
     db = 10 * torch.log10(ga.pow(2).sum() / (ga - gb).pow(2).sum().clamp_min(1e-300))
     assert float(db) > 110, float(db)
