@@ -74,7 +74,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-PMC_TABLE = os.path.join(ROOT, "profiles", "r03_h_pmc_traffic.json")
+PMC_TABLE = os.path.join(ROOT, "profiles", "r03_j_pmc_traffic.json")
 PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r03_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
 
 
