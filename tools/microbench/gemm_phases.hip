@@ -128,5 +128,16 @@ int main() {
     auto kern2 = gemm_ws_kernel<128, 4, 1, 4, ALoadSeqTile, EpiLstmPre16NoStore, false>;
     run("K4 without its stores", kern2, lds, 256, g.nst * g.len, W4, N, queue, al, ep2, seg);
   }
+  {   // training: d x = d_out + dP W_ih (K = 512 gate columns of one direction -> 128), the largest kernel of a training step
+    float *DG, *DX, *W5;
+    hipMalloc(&DG, (M + 32) * 1024 * 4); hipMemset(DG, 0, (M + 32) * 1024 * 4);
+    hipMalloc(&DX, (M + 32) * 128 * 4); hipMemset(DX, 0, (M + 32) * 128 * 4);
+    hipMalloc(&W5, 512 * 128 * 4); hipMemset(W5, 0, 512 * 128 * 4);
+    ALoadCols al{DG, M, 1024, 0, 32};
+    EpiAddMaskStoreT<true, false> ep{DX, X, nullptr, M, N, 32, N};
+    auto kern = gemm_ws_kernel<512, 1, 1, 4, ALoadCols, EpiAddMaskStoreT<true, false>, true>;
+    const size_t lds = GemmShape<512, 1, 1, 4>::lds_bytes(false);
+    run("dgrad dP W_ih (K = 512)", kern, lds, 256, ntiles, W5, N, queue, al, ep, seg);
+  }
   return 0;
 }
