@@ -49,6 +49,14 @@ template <class E>
 struct has_prefetch2<E, std::void_t<decltype(std::declval<const E&>().prefetch2(0, 0, 0))>> : std::true_type {};
 // DIRECT epilogues may offer `float direct_const(colgroup, cb, c)` (e.g. the scaled bias of the lane's column): loaded
 // once per workgroup and handed to store_acc instead of two dependent global loads per column block and tile.
+// Epi::FOLD (DIRECT epilogues of the form acc * col_scale + direct_const): the engine folds the scale into the weight
+// fragments when it loads them and the constant into the accumulators' start (one extra MFMA: ones x constant), so the
+// epilogue is 16-byte stores straight from the accumulator registers -- no per-element fma, no AGPR -> VGPR moves
+// (64 + 64 instructions per K4 tile beside fp32 MFMAs, where every vector instruction costs its issue time).
+template <class E, class = void>
+struct epi_folds : std::false_type {};
+template <class E>
+struct epi_folds<E, std::enable_if_t<E::FOLD>> : std::true_type {};
 template <class E, class = void>
 struct has_direct_const : std::false_type {};
 template <class E>
@@ -246,6 +254,16 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     }
   }
 
+  constexpr bool FOLD = !SPLIT && !WT && epi_folds<Epi>::value;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float cs = epi.col_scale(wc * NT + nt);
+#pragma unroll
+      for (int k = 0; k < Sh::KS; ++k) wf[nt][k] *= cs;
+    }
+  }
+
   constexpr int K4 = KIN / 4;                       // float4 per A row
   constexpr int NLD = (Sh::BM * K4) / 256;          // float4 loads per thread per tile
   static_assert((Sh::BM * K4) % 256 == 0, "tile/threads");
@@ -277,6 +295,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   if constexpr (Epi::DIRECT && has_direct_const<Epi>::value) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) dconst[nt] = epi.direct_const(colgroup, wc * NT + nt, c);
+  }
+  // FOLD: the constant enters as D = ones x const: A fragment (row c, k-slot hh) = [1, 0], B fragment (k-slot hh, column c) =
+  // [const, 0] -> every row of the tile starts from its column's constant
+  const float fold_one = hh == 0 ? 1.0f : 0.0f;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dconst[nt] = hh == 0 ? dconst[nt] : 0.0f;
   }
 
   TileTickets tickets{tile_queue ? tile_queue + colgroup : nullptr, (int)blockIdx.x, (int)gridDim.x};
@@ -389,7 +414,10 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     // ---- A fragments + MFMA --------------------------------------------------------------------
     f32x16 acc[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = zero16();
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (FOLD) acc[nt] = mfma32(fold_one, dconst[nt], zero16());
+      else acc[nt] = zero16();
+    }
     f32x16 acc_odd = zero16();   // (PIN only)
     if constexpr (SPLIT) {
       const int rowoff = buf * (Sh::BM * Sh::LDAB) + (wr * 32 + c) * Sh::LDAB + 8 * hh;
@@ -483,7 +511,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     if constexpr (Epi::DIRECT) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        if constexpr (has_direct_const<Epi>::value) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh, dconst[nt]);
+        if constexpr (FOLD) epi.store_raw(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
+        else if constexpr (has_direct_const<Epi>::value) epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh, dconst[nt]);
         else epi.store_acc(tile, wr, colgroup, wc * NT + nt, acc[nt], c, hh);
       }
     } else {
@@ -829,6 +858,15 @@ struct EpiLstmPre {
     const int j = cb * 32 + c;
     return (b_ih[d][j] + b_hh[d][j]) * lstm_gate_scale(cb >> 2);
   }
+  static constexpr bool FOLD = true;   // fp32 engine: scale folded into W_ih's fragments, bias into the accumulators' start
+  DEV float col_scale(int cb) const { return lstm_gate_scale(cb >> 2); }
+  DEV void store_raw(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
+    const int st = tile / g.len, t = tile - st * g.len;
+    float* base = pre + pre_tile_offset(d, st, t, g.nst, g.len) + (int64_t)cb * 1024 + hh * 128 + c * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(base + q * 256) = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  }
   DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh, float bias) const {
     const int st = tile / g.len, t = tile - st * g.len;
     const float gs = lstm_gate_scale(cb >> 2);
@@ -863,6 +901,20 @@ struct EpiLstmPre16 {
   DEV float direct_const(int d, int cb, int c) const {
     const int j = cb * 32 + c;
     return (b_ih[d][j] + b_hh[d][j]) * l16_gate_scale(cb >> 2);
+  }
+  static constexpr bool FOLD = true;   // fp32 engine: scale folded into W_ih's fragments, bias into the accumulators' start
+  DEV float col_scale(int cb) const { return l16_gate_scale(cb >> 2); }
+  DEV void store_raw(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh) const {
+    const int st = tile / g.len, t = tile - st * g.len;
+    const int gate = cb >> 2;
+    const int lane_off = (c >> 4) * 256 + (hh * 16 + (c & 15)) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int st16 = 2 * st + (q >> 1);
+      if (st16 >= nst16) continue;   // a 16-sequence tile made of padding only
+      float* ubase = pre + pre16_tile_offset(d, st16, t, nst16, g.len) + (cb & 3) * 2048 + 2 * gate * 256 + (q & 1) * 128;
+      *reinterpret_cast<float4*>(ubase + lane_off) = make_float4(acc[4 * q + 0], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
   }
   DEV void store_acc(int tile, int /*wr*/, int d, int cb, const f32x16& acc, int c, int hh, float bias) const {
     const int st = tile / g.len, t = tile - st * g.len;
