@@ -26,6 +26,7 @@
 
 // phase stamps for tools/microbench/gemm_phases.hip (a diagnostic build defines these; the product build does not)
 #ifndef GEMM_STAMP
+#define GEMM_STAMP_ENTRY
 #define GEMM_STAMP_DECL
 #define GEMM_STAMP(i)
 #define GEMM_STAMP_ACC(i, x)
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
                                                        Rider rider = Rider{}) {
   using Sh = GemmShape<KIN, NT, WR, WC>;
   static_assert(WR * WC == 4, "4 waves");
+  GEMM_STAMP_ENTRY
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_next = reinterpret_cast<int*>(smem);       // [2] tile tickets (double buffered), 16-byte slot
   float* As = smem + 4;

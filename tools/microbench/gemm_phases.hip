@@ -8,9 +8,11 @@
 __device__ unsigned long long* g_seg;
 #define GEMM_STAMP 1
 // per-wave accumulators in registers, written once at the end (a stamp costs one s_memtime + a 64-bit add)
+#define GEMM_STAMP_ENTRY const unsigned long long t_entry_ = __builtin_amdgcn_s_memtime();
 #define GEMM_STAMP_DECL                                   \
-  unsigned long long seg_[6] = {0, 0, 0, 0, 0, 0};       \
-  unsigned long long t_last_ = __builtin_amdgcn_s_memtime();
+  unsigned long long seg_[7] = {0, 0, 0, 0, 0, 0, 0};    \
+  unsigned long long t_last_ = __builtin_amdgcn_s_memtime(); \
+  seg_[6] = t_last_ - t_entry_;   /* prologue: weight fragments, first ticket, first A tile requested */
 #define GEMM_STAMP(i)                                                 \
   do {                                                                \
     const unsigned long long n_ = __builtin_amdgcn_s_memtime();       \
@@ -24,7 +26,7 @@ __device__ unsigned long long* g_seg;
   } while (0)
 #define GEMM_STAMP_END                                                                                       \
   if ((threadIdx.x & 63) == 0) {                                                                             \
-    for (int i_ = 0; i_ < 6; ++i_) g_seg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = seg_[i_];  \
+    for (int i_ = 0; i_ < 7; ++i_) g_seg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = seg_[i_];  \
   }
 #include "gemm_ws.h"
 #include "backward.h"
@@ -61,14 +63,14 @@ void run(const char* name, Kern kern, size_t lds, int wgs, int ntiles, const flo
   }
   std::vector<unsigned long long> h((size_t)wgs * 32);
   hipMemcpy(h.data(), seg, h.size() * 8, hipMemcpyDeviceToHost);
-  double s[6] = {0, 0, 0, 0, 0, 0};
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int w = 0; w < wgs * 4; ++w)
-    for (int i = 0; i < 6; ++i) s[i] += (double)h[(size_t)w * 8 + i];
+    for (int i = 0; i < 7; ++i) s[i] += (double)h[(size_t)w * 8 + i];
   const double per = (double)ntiles * 4;   // wave-tiles
   printf("%-26s %4d WGs %.3f ms | cycles per tile and wave: ticket + A->LDS %.0f  barrier %.0f  prefetch issue %.0f  frag+MFMA %.0f  "
-         "C->LDS+barrier %.0f  epilogue %.0f | sum %.0f\n",
+         "C->LDS+barrier %.0f  epilogue %.0f | sum %.0f | prologue per wave %.0f cycles, %.1f tiles per workgroup\n",
          name, wgs, ms, s[0] / per, s[1] / per, s[2] / per, s[3] / per, s[4] / per, s[5] / per,
-         (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / per);
+         (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / per, s[6] / (wgs * 4.0), (double)ntiles / wgs);
 }
 
 int main() {
