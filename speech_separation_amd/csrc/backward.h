@@ -152,9 +152,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
   for (int k = 0; k < NCS; ++k) csum[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   TileTickets tickets{queue, (int)blockIdx.x, (int)gridDim.x};
   int ticket_ahead = 0;
-  if (tid == 0) {
-    s_next[0] = tickets.take();
-    ticket_ahead = tickets.take();
+  if (tickets.dynamic()) {
+    if (tid == 0) {
+      s_next[0] = tickets.take();
+      ticket_ahead = tickets.take();
+    }
+  } else if (tid == 0) {
+    s_next[0] = tickets.first;
   }
   __syncthreads();
   int tile = s_next[0];
@@ -187,11 +191,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int ntiles, unsigned* __rest
       const int idx = i * 256 + tid;
       *reinterpret_cast<float4*>(&Xs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = px[i];
     }
-    if (tid == 0) s_next[par ^ 1] = ticket_ahead;   // publish the next ticket (requested one tile ago)
+    if (tickets.dynamic() && tid == 0) s_next[par ^ 1] = ticket_ahead;   // publish the next ticket (requested one tile ago)
     __syncthreads();
-    const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
+    const int next = tickets.dynamic() ? __builtin_amdgcn_readfirstlane(s_next[par ^ 1]) : tile + tickets.stride;
     const int nf = next < ntiles ? next : ntiles - 1;
-    if (tid == 0) ticket_ahead = tickets.take();
+    if (tickets.dynamic() && tid == 0) ticket_ahead = tickets.take();
     // D[i = row of dW][j = col of dW] += sum over the tile's tokens; MFMA step s covers tokens 2s (slot 0), 2s+1 (slot 1)
     float a[2][Sh::RB], b[2][Sh::CB];
     auto frag = [&](int s, float* fa, float* fb) {
@@ -361,9 +365,13 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
   float4 py[NY], pxa[NX], pxb[NX];
   TileTickets tickets{queue, wg, (int)gridDim.x / NSL};
   int ticket_ahead = 0;
-  if (tid == 0) {
-    s_next[0] = tickets.take();
-    ticket_ahead = tickets.take();
+  if (tickets.dynamic()) {
+    if (tid == 0) {
+      s_next[0] = tickets.take();
+      ticket_ahead = tickets.take();
+    }
+  } else if (tid == 0) {
+    s_next[0] = tickets.first;
   }
   __syncthreads();
   int tile = s_next[0];
@@ -392,11 +400,11 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(int ntiles, unsigned* __res
       *reinterpret_cast<float4*>(&Xas[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = pxa[i];
       *reinterpret_cast<float4*>(&Xbs[(idx / X4) * Sh::LDX + 4 * (idx % X4)]) = pxb[i];
     }
-    if (tid == 0) s_next[par ^ 1] = ticket_ahead;
+    if (tickets.dynamic() && tid == 0) s_next[par ^ 1] = ticket_ahead;
     __syncthreads();
-    const int next = __builtin_amdgcn_readfirstlane(s_next[par ^ 1]);
+    const int next = tickets.dynamic() ? __builtin_amdgcn_readfirstlane(s_next[par ^ 1]) : tile + tickets.stride;
     const int nf = next < ntiles ? next : ntiles - 1;
-    if (tid == 0) ticket_ahead = tickets.take();
+    if (tickets.dynamic() && tid == 0) ticket_ahead = tickets.take();
     float a[2][Sh::RB], ba[2][Sh::CB], bb[2][Sh::CB];
     auto frag = [&](int s, float* fa, float* fba, float* fbb) {
       const float* yrow = Ys + (2 * s + hh) * Sh::LDY + c;

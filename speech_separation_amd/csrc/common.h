@@ -178,16 +178,14 @@ DEV int64_t pre_tile_offset(int d, int st, int t, int nst, int len) {
 // the host), so a workgroup that starts late -- the kernel shares the chip with another stream's -- simply finds fewer
 // tiles left.  With queue == nullptr (option "deterministic") the static sequence first, first + stride, ...: WHICH
 // workgroup sums WHICH tiles is then fixed, and so is the rounding of every token reduction (bias / weight gradients).
-// Used by thread 0 only; `queue` is wave-uniform (a kernel argument), so the branch is scalar.
+// `queue` is a kernel argument, so `dynamic()` is wave-uniform.  The static sequence never goes through the ticket register
+// or LDS (every wave computes tile + stride itself): sharing the register with the atomic's result made the compiler wait
+// for "a possibly outstanding atomic" before every static update, i.e. for the A-tile prefetch just issued.
 struct TileTickets {
   unsigned* queue;
-  int next, stride;
-  DEV int take() {
-    if (queue) return (int)atomicAdd(queue, 1u);
-    const int t = next;
-    next += stride;
-    return t;
-  }
+  int first, stride;
+  DEV bool dynamic() const { return queue != nullptr; }
+  DEV int take() const { return (int)atomicAdd(queue, 1u); }   // dynamic() only, one lane
 };
 
 // Host helper: "done once per HIP device" flags for function attributes (hipFuncSetAttribute applies to the device

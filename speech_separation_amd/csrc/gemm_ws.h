@@ -308,9 +308,13 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
 
   TileTickets tickets{tile_queue ? tile_queue + colgroup : nullptr, (int)blockIdx.x, (int)gridDim.x};
   int ticket_ahead = 0;
-  if (tid == 0) {
-    s_next[0] = tickets.take();
-    ticket_ahead = tickets.take();
+  if (tickets.dynamic()) {
+    if (tid == 0) {
+      s_next[0] = tickets.take();
+      ticket_ahead = tickets.take();
+    }
+  } else if (tid == 0) {
+    s_next[0] = tickets.first;
   }
   __syncthreads();
   float4 pf[NLD];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
   GEMM_STAMP_DECL
   while (tile < ntiles) {
     float* Ab = As + buf * (Sh::BM * Sh::LDA);
-    if (tid == 0) s_next[buf ^ 1] = ticket_ahead;              // publish the next ticket (requested one tile ago)
+    if (tickets.dynamic() && tid == 0) s_next[buf ^ 1] = ticket_ahead;   // publish the next ticket (requested one tile ago)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = i * 256 + tid;
@@ -386,7 +390,8 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     __syncthreads();   // also orders the previous iteration's Cs reads before this iteration's Cs writes
     GEMM_STAMP(1);
 
-    const int next = __builtin_amdgcn_readfirstlane(s_next[buf ^ 1]);   // wave-uniform: scalar address arithmetic
+    // wave-uniform: scalar address arithmetic
+    const int next = tickets.dynamic() ? __builtin_amdgcn_readfirstlane(s_next[buf ^ 1]) : tile + tickets.stride;
     if (next < ntiles) load_tile(next);
     // epilogue operands that do not depend on the product (residual rows ...) are requested now as well
     float4 epf[NPASS];
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
     // request the ticket after the next one HERE, in front of the MFMA block: issued at the loop top it was the youngest
     // memory operation when the A-tile registers are waited for (s_waitcnt vmcnt(0)), i.e. wave 0 sat out the atomic's
     // round trip every tile and the other waves waited for it at the barrier (~1 k cycles per tile)
-    if (tid == 0) ticket_ahead = tickets.take();
+    if (tickets.dynamic() && tid == 0) ticket_ahead = tickets.take();
     // The ticket must stay in a VGPR until it is published at the top of the next iteration.  These kernels fill the
     // register file, and where the allocator parked `ticket_ahead` in an AGPR (a register spill) it had to wait for the
     // atomic's result RIGHT HERE to copy it over -- s_waitcnt vmcnt(0) behind the A-tile prefetch, i.e. the prefetch's HBM

@@ -10,6 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("AB_LIB"):          # A/B of two builds of the library: AB_LIB=<path to the other .so>
+    import speech_separation_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
 from speech_separation_amd import DPTNAVWavEncDec  # noqa: E402
 from speech_separation_amd.spec import DPTN_AV, synthetic_inputs, synthetic_state_dict  # noqa: E402
 from speech_separation_amd.train import FusedAdamW, SiSNRWavLoss, train_step  # noqa: E402
