@@ -38,7 +38,7 @@ constexpr int QUEUE_SLOTS = 1024;
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, wih, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -51,6 +51,7 @@ struct Run {
   hipEvent_t lstm_wait = nullptr;    // if set: the recurrence launch waits for this event (other half's recurrence)
   hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
   int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
+  bool packed_wih = false;           // ws + pl.wih holds the fragment-order W_ih copies of ALL paths; otherwise run_path packs its own
   bool packed = false;               // ws + pl.wpack holds the packed weights of ALL paths (dptnav_forward); otherwise
                                      // run_path packs the path it is about to run
   unsigned* take_queue(int n) {
@@ -79,6 +80,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
   bool opt_deterministic = false;   // 1: static tile assignment instead of device-wide tickets (TileTickets): bit-reproducible gradients
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
@@ -360,6 +362,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->wfold = take((size_t)8 * 2 * N + 8);   // folded decoder weights [G | W_dec^T | bd] (run_tail)
   // fragment-order copies of the attention / FFN weights of every path for the fused attention block (attn_block.h)
   p->wpack = take(g.arch == 0 && N == 128 ? (size_t)2 * g.num_blocks * ATTN_PACK_FLOATS : 0);
+  // fragment-order copies of W_ih (both directions) of every path for the K4 launches (gemm_ws.h, ldw == 0)
+  p->wih = take((size_t)2 * g.num_blocks * 2 * 4 * H * N);
   p->total = o;
   return DPTNAV_OK;
 }
@@ -514,6 +518,38 @@ static int pack_attn_weights(dptnav_ctx* c, hipStream_t st, int first, int n, fl
   return DPTNAV_OK;
 }
 
+// fragment-order copies of W_ih (forward, reverse) of paths [first, first + n) -> dst[(path - first)][2][512 x N]
+template <int N>
+static int pack_wih(dptnav_ctx* c, hipStream_t st, int first, int n, float* dst) {
+  GemmPackArgs a;
+  for (int i = 0; i < GEMM_PACK_MAX; ++i) a.src[i] = nullptr;
+  if (2 * n > GEMM_PACK_MAX) return c->fail(DPTNAV_ERR_INVALID, "W_ih pack: %d paths in one launch", n);
+  for (int i = 0; i < n; ++i) {
+    const PathWeights& w = c->pw[first + i];
+    a.src[2 * i] = w.w_ih[0];
+    a.src[2 * i + 1] = w.ndir == 2 ? w.w_ih[1] : nullptr;
+  }
+  a.rows = 4 * LSTM_H;
+  a.K = N;
+  hipLaunchKernelGGL(gemm_pack_rows_kernel, dim3(16, 2 * n), dim3(256), 0, st, a, dst);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "W_ih pack: %s", hipGetErrorString(e));
+  return DPTNAV_OK;
+}
+
+// all paths of the model into run.ws + pl.wih (dptnav_forward / dptnav_train_forward: once per pass and sub-batch)
+template <int N>
+static int pack_wih_all(dptnav_ctx* c, Run& run) {
+  if (!c->opt_pack_wih) return DPTNAV_OK;
+  const int npaths = 2 * c->cfg.num_blocks;
+  for (int first = 0; first < npaths; first += GEMM_PACK_MAX / 2) {
+    const int n = std::min(GEMM_PACK_MAX / 2, npaths - first);
+    if (int rc = pack_wih<N>(c, run.st, first, n, run.ws + run.pl.wih + (size_t)first * 2 * (4 * LSTM_H * N))) return rc;
+  }
+  run.packed_wih = true;
+  return DPTNAV_OK;
+}
+
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
              const PathBufs* bufs = nullptr, int chain = 0) {
@@ -613,18 +649,29 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     ALoadSeqTile al{lstm_in, N, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
     int rc;
+    // fp32 form: W_ih from its fragment-order copy (made for all paths at the start of the pass, or here for this path)
+    const float *wih0 = w.w_ih[0], *wih1 = w.w_ih[1];
+    int ldw_ih = N;
+    if (c->opt_pack_wih && !split) {
+      float* pk = ws + pl.wih + (size_t)(2 * block + path) * 2 * (4 * LSTM_H * N);
+      if (!run.packed_wih)
+        if (int rcp = pack_wih<N>(c, st, 2 * block + path, 1, pk)) return rcp;
+      wih0 = pk;
+      wih1 = pk + 4 * LSTM_H * N;
+      ldw_ih = 0;
+    }
     if (use16 && split) {   // opt-in split-precision mode (bf16 hi/lo operands, fp32 accumulation)
       EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
       rc = launch_gemm<N, 4, 1, 4, false, true>(c, run, CAT_LSTM_PRE, "lstm-pre gemm (split)", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
     } else if (use16) {
       EpiLstmPre16 ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom, nst16};
-      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", wih0, nt4, w.ndir, al, ep, wih1, ldw_ih);
     } else if (split) {
       EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
       rc = launch_gemm<N, 4, 1, 4, false, true>(c, run, CAT_LSTM_PRE, "lstm-pre gemm (split)", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
     } else {
       EpiLstmPre ep{pre, {w.b_ih[0], w.b_ih[1]}, {w.b_hh[0], w.b_hh[1]}, geom};
-      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", w.w_ih[0], nt4, w.ndir, al, ep, w.w_ih[1]);
+      rc = launch_gemm<N, 4, 1, 4>(c, run, CAT_LSTM_PRE, "lstm-pre gemm", wih0, nt4, w.ndir, al, ep, wih1, ldw_ih);
     }
     if (rc) return rc;
   }
@@ -1642,6 +1689,7 @@ int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st
   run->st = st;
   run->slot = 0;
   run->packed = false;
+  run->packed_wih = false;
   hipError_t e = hipMemsetAsync(ws + pl.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st);
   if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "ticket counter reset: %s", hipGetErrorString(e));
   return DPTNAV_OK;
@@ -1936,6 +1984,8 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
       if (int rc2 = pack_attn_weights(h, run[i].st, 0, 2 * g.num_blocks, run[i].ws + run[i].pl.wpack)) return rc2;
       run[i].packed = true;
     }
+    if (!h->opt_split_bf16)
+      if (int rc2 = big ? pack_wih_all<128>(h, run[i]) : pack_wih_all<64>(h, run[i])) return rc2;
   }
   // recurrence launch n (path-major, sub-batch minor) waits for launch n - depth: `depth` recurrences may be in flight
   // (forward_split; > 1 pays when two launches fit the chip together: three or more sub-batches).  ev_sub[j] is re-recorded by sub-batch j once per path, so its latest record IS launch n - depth.
@@ -2250,6 +2300,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
                                sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid) : run_head<64>(h, run[i], mix + b0[i] * T, e1 ? e1 + b0[i] * Cv * Tv : nullptr, e2 ? e2 + b0[i] * Cv * Tv : nullptr,
                                sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid)))
       return rc;
+    if (int rc = h->cfg.num_features == 128 ? pack_wih_all<128>(h, run[i]) : pack_wih_all<64>(h, run[i])) return rc;
   }
   // the halves advance in lock step on the host; their recurrences are chained by events as in dptnav_forward
   bool have_prev = false;
@@ -2424,6 +2475,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "deterministic") h->opt_deterministic = value != 0;
+  else if (k == "pack_wih") h->opt_pack_wih = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {
     if (value < 0 || value > 2) return h->fail(DPTNAV_ERR_INVALID, "lstm4: 0, 1 or 2");

@@ -238,10 +238,16 @@ __global__ __launch_bounds__(256) void gemm_ws_kernel(const float* __restrict__ 
         }
       }
     } else if constexpr (!WT) {
-      const float* wrow = Wsel + (int64_t)j * ldw + 4 * hh;
+      // ldw == 0: W is a FRAGMENT-ORDER copy (gemm_pack_rows_kernel: [column block 32][k chunk 8][lane 64][4]) -- a wave's
+      // fragment load is 1 KiB contiguous.  Straight from a row-major tensor it is row-per-lane: 32 cache lines per wave
+      // instruction, and the prologue of a workgroup that loads a 512-column slice costs 24 k cycles (1.2 tiles' worth,
+      // tools/microbench/gemm_phases) against ~6 k from the copy.  Same values either way: bit-identical results.
+      const float* wrow = ldw == 0 ? Wsel + ((int64_t)(j >> 5) * (KIN / 8)) * 256 + 4 * (hh * 32 + c)
+                                   : Wsel + (int64_t)j * ldw + 4 * hh;
+      const int mstep = ldw == 0 ? 256 : 8;
 #pragma unroll
       for (int m = 0; m < KIN / 8; ++m) {
-        const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * m);
+        const float4 v = *reinterpret_cast<const float4*>(wrow + mstep * m);
         wf[nt][4 * m + 0] = v.x;
         wf[nt][4 * m + 1] = v.y;
         wf[nt][4 * m + 2] = v.z;
@@ -1074,3 +1080,23 @@ struct EpiLNBackward {
     }
   }
 };
+
+// ------------------------------------------------------------------------------------------------
+// fragment-order copies of row-major weight matrices W[rows][K] (rows % 32 == 0, K % 8 == 0) for the engine's ldw == 0 form:
+//   dst[matrix][column block cb = row / 32][k chunk m = k / 8][lane = 32 hh + c][4] = W[32 cb + c][8 m + 4 hh .. + 3]
+// ------------------------------------------------------------------------------------------------
+constexpr int GEMM_PACK_MAX = 24;
+struct GemmPackArgs {
+  const float* src[GEMM_PACK_MAX];   // nullptr: that slot stays untouched (a path without a reverse direction)
+  int rows, K;
+};
+__global__ __launch_bounds__(256) void gemm_pack_rows_kernel(GemmPackArgs a, float* __restrict__ dst) {
+  const float* W = a.src[blockIdx.y];
+  if (W == nullptr) return;
+  const int km = a.K / 8, n4 = a.rows * a.K / 4;
+  float4* out = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * a.rows * a.K);
+  for (int f = blockIdx.x * 256 + threadIdx.x; f < n4; f += gridDim.x * 256) {
+    const int lane = f & 63, m = (f >> 6) % km, cb = (f >> 6) / km;
+    out[f] = *reinterpret_cast<const float4*>(W + (size_t)(32 * cb + (lane & 31)) * a.K + 8 * m + 4 * (lane >> 5));
+  }
+}

@@ -29,6 +29,9 @@ train_step(model, dict(batch0), crit, opt, 10.0)
 eng = model._engine
 defaults = {"wgrad_side": 1, "wgrad_ride": 1, "lstm_chain": 0, "ln_tape": 1, "wgrad2": 1, "lstm16": 1, "deterministic": 0}
 cases = [{}] + [{k: 1 - v} for k, v in defaults.items()] + [{"wgrad_side": 0, "lstm_chain": 1}]
+if len(sys.argv) > 1 and sys.argv[1] == "pack":
+    defaults["pack_wih"] = 1
+    cases = [{}, {"pack_wih": 0}, {}, {"pack_wih": 0}, {}, {"pack_wih": 0}]
 if len(sys.argv) > 1 and sys.argv[1] == "det":
     cases = [{}, {"deterministic": 1}, {}, {"deterministic": 1}]
 if len(sys.argv) > 1 and sys.argv[1] == "side":
