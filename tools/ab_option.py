@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
+if os.environ.get("AB_LIB"):          # A/B of two BUILDS: AB_LIB=<path to the other .so>, run the script once per build
+    import speech_separation_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
 from speech_separation_amd.engine import DptnEngine, params_to_device  # noqa: E402
 from speech_separation_amd.spec import DPTN_AUDIO, DPTN_AV, synthetic_inputs, synthetic_state_dict  # noqa: E402
 
