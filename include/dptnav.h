@@ -258,6 +258,8 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 a training step: a workgroup that starts late, beside another stream's kernel, keeps its share.
  *   "pack_wih" (0/1, default 1): the LSTM pre-activation GEMM reads W_ih from a fragment-order copy made at the start of
  *                 every pass (coalesced fragment loads in every workgroup's prologue); bit-identical to 0.
+ *   "pack_whh" (0/1, default 1): the low-latency recurrence (lstm4) reads W_hh from a fragment-order copy made at its
+ *                 first launch of a pass; bit-identical to 0.
  *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a
  *                 step takes ~1.2 us instead of ~4.3 us, four times the workgroups) for inference launches of at most
  *                 1.15 rounds of the chip -- bs = 1..3 whole, sub-batches of up to 4 mixtures at 4 s; 2 = wherever

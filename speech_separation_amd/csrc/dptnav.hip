@@ -38,7 +38,7 @@ constexpr int QUEUE_SLOTS = 1024;
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, wih, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, wih, whh4, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -51,6 +51,7 @@ struct Run {
   hipEvent_t lstm_wait = nullptr;    // if set: the recurrence launch waits for this event (other half's recurrence)
   hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
   int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
+  bool packed_whh4 = false;          // ws + pl.whh4 holds the fragment-order W_hh copies of ALL paths for lstm4.hip (made at its first launch of the pass)
   bool packed_wih = false;           // ws + pl.wih holds the fragment-order W_ih copies of ALL paths; otherwise run_path packs its own
   bool packed = false;               // ws + pl.wpack holds the packed weights of ALL paths (dptnav_forward); otherwise
                                      // run_path packs the path it is about to run
@@ -80,6 +81,7 @@ struct dptnav_ctx {
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
   bool opt_lstm16 = true;
+  bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
   bool opt_deterministic = false;   // 1: static tile assignment instead of device-wide tickets (TileTickets): bit-reproducible gradients
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
@@ -364,6 +366,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->wpack = take(g.arch == 0 && N == 128 ? (size_t)2 * g.num_blocks * ATTN_PACK_FLOATS : 0);
   // fragment-order copies of W_ih (both directions) of every path for the K4 launches (gemm_ws.h, ldw == 0)
   p->wih = take((size_t)2 * g.num_blocks * 2 * 4 * H * N);
+  // ... and of W_hh in the order of the low-latency recurrence (lstm4.hip, `packed`)
+  p->whh4 = take((size_t)2 * g.num_blocks * 2 * 4 * H * H);
   p->total = o;
   return DPTNAV_OK;
 }
@@ -683,9 +687,25 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     const int rc = lstm16s_launch(c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16s: %s", hipGetErrorString((hipError_t)rc));
   } else if (use4) {
+    const float *whh0 = w.w_hh[0], *whh1 = w.w_hh[1];
+    if (c->opt_pack_whh && 2 * (int)c->pw.size() <= LSTM4_PACK_MAX) {
+      float* base = ws + pl.whh4;
+      if (!run.packed_whh4) {   // first 4-sequence recurrence of this pass: copy every path's W_hh, one launch
+        const float* src[LSTM4_PACK_MAX];
+        for (size_t i = 0; i < c->pw.size(); ++i) {
+          src[2 * i] = c->pw[i].w_hh[0];
+          src[2 * i + 1] = c->pw[i].ndir == 2 ? c->pw[i].w_hh[1] : nullptr;
+        }
+        const int rcp = lstm4_pack_launch(st, src, 2 * (int)c->pw.size(), base);
+        if (rcp != 0) return c->fail(DPTNAV_ERR_HIP, "lstm4 W_hh pack: %s", hipGetErrorString((hipError_t)rcp));
+        run.packed_whh4 = true;
+      }
+      whh0 = base + (size_t)(2 * (2 * block + path)) * (4 * LSTM_H * LSTM_H);
+      whh1 = whh0 + 4 * LSTM_H * LSTM_H;
+    }
     ProfScope ps(c, CAT_LSTM, st);
-    const int rc = lstm4_launch(c->cfg.arch == 0, nst4, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc,
-                                w.ndir * LSTM_H, (int)M, geom);
+    const int rc = lstm4_launch(c->cfg.arch == 0, nst4, nst16, w.ndir, st, pre, whh0, whh1, hc,
+                                w.ndir * LSTM_H, (int)M, geom, whh0 != w.w_hh[0]);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm4: %s", hipGetErrorString((hipError_t)rc));
   } else if (use16) {
     // lstm_stamps: diagnostic builds; lstm_diag > 0 are timing-only ablations (wrong results), see lstm16.hip
@@ -1690,6 +1710,7 @@ int begin_run(dptnav_ctx* c, Run* run, float* ws, const Plan& pl, hipStream_t st
   run->slot = 0;
   run->packed = false;
   run->packed_wih = false;
+  run->packed_whh4 = false;
   hipError_t e = hipMemsetAsync(ws + pl.queue, 0, QUEUE_SLOTS * sizeof(unsigned), st);
   if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "ticket counter reset: %s", hipGetErrorString(e));
   return DPTNAV_OK;
@@ -2476,6 +2497,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "overlap") h->opt_overlap = value != 0;
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
+  else if (k == "pack_whh") h->opt_pack_whh = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {
     if (value < 0 || value > 2) return h->fail(DPTNAV_ERR_INVALID, "lstm4: 0, 1 or 2");

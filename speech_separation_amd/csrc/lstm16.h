@@ -51,4 +51,8 @@ int lstm32s_launch(bool relu, int nst, int ndir, void* stream, const float* pre,
 // stands (nst16 = its tile count), one workgroup per direction and 4 sequences, nst4 = ceil(sequences / 4).  Inference
 // only.
 int lstm4_launch(bool relu, int nst4, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
-                 const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g);
+                 const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, bool packed = false);
+// `packed`: whh_f / whh_b are fragment-order copies made by this launch (n <= LSTM4_PACK_MAX matrices of 512 x 128, nullptr
+// entries skipped) -> dst[n][512 * 128]
+constexpr int LSTM4_PACK_MAX = 24;
+int lstm4_pack_launch(void* stream, const float* const* src, int n, float* dst);

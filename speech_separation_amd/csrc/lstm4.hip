@@ -46,7 +46,7 @@ constexpr size_t L4_LDS_BYTES = sizeof(float) * L4_HS_FLOATS;
 template <bool RELU, int NCH = 1>
 __global__ __launch_bounds__(256) void lstm4_kernel(const float* __restrict__ pre, const float* __restrict__ whh_f,
                                                      const float* __restrict__ whh_b, float* __restrict__ hc, int ldh,
-                                                     int dump_row, SeqGeom g, int nst16) {
+                                                     int dump_row, SeqGeom g, int nst16, int packed) {
   __shared__ __attribute__((aligned(16))) float Hs[L4_HS_FLOATS];
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,18 +55,21 @@ __global__ __launch_bounds__(256) void lstm4_kernel(const float* __restrict__ pr
   const float* whh = d ? whh_b : whh_f;
   const int unit = 32 * w + c32;
 
-  // W_hh rows of the lane's two gate columns, scaled for the exp2 forms of sigmoid / tanh
+  // W_hh rows of the lane's two gate columns, scaled for the exp2 forms of sigmoid / tanh.  From the nn.Module tensor a
+  // wave instruction touches 64 rows = 64 cache lines (16 k cycles of address processing per workgroup, ~7 us of a 170 us
+  // launch); `packed`: from the copy lstm4_pack_launch makes once per pass, [wave][group][q][lane][4] -- 1 KiB contiguous.
   float wf[2][128];
 #pragma unroll
   for (int grp = 0; grp < 2; ++grp) {
     const int gate = 2 * grp + up;
-    const float* wrow = whh + (int64_t)(gate * L16_H + unit) * L16_H;
+    const float* wrow = packed ? whh + ((w * 2 + grp) * 32) * 256 + lane * 4 : whh + (int64_t)(gate * L16_H + unit) * L16_H;
+    const int qstep = packed ? 256 : 4;
     const float gs = l16_gate_scale(gate);
 #pragma unroll
     for (int piece = 0; piece < 4; ++piece) {   // handed to the AGPR half in pieces (all 256 at once would spill)
 #pragma unroll
       for (int q = 8 * piece; q < 8 * piece + 8; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(wrow + 4 * q);
+        const float4 v = *reinterpret_cast<const float4*>(wrow + qstep * q);
         wf[grp][4 * q + 0] = v.x * gs;
         wf[grp][4 * q + 1] = v.y * gs;
         wf[grp][4 * q + 2] = v.z * gs;
@@ -178,11 +181,34 @@ __global__ __launch_bounds__(256) void lstm4_kernel(const float* __restrict__ pr
 }
 
 int lstm4_launch(bool relu, int nst4, int nst16, int ndir, void* stream, const float* pre, const float* whh_f,
-                 const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g) {
-  using Kern = void (*)(const float*, const float*, const float*, float*, int, int, SeqGeom, int);
+                 const float* whh_b, float* hc, int ldh, int dump_row, const SeqGeom& g, bool packed) {
+  using Kern = void (*)(const float*, const float*, const float*, float*, int, int, SeqGeom, int, int);
   const Kern kern = relu ? lstm4_kernel<true> : lstm4_kernel<false>;
   if (nst4 < 1 || nst4 > 4 * nst16) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3(nst4, ndir), dim3(256), 0, static_cast<hipStream_t>(stream), pre, whh_f, whh_b, hc, ldh, dump_row,
-                     g, nst16);
+                     g, nst16, packed ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+// Fragment-order copies of up to LSTM4_PACK_MAX W_hh matrices ([512][128], gate-major rows) for lstm4_kernel's `packed` form:
+//   dst[matrix][wave 4][group 2][q 32][lane 64][4] = W_hh[(2 group + (lane >> 5)) * 128 + 32 wave + (lane & 31)][4 q .. 4 q + 3]
+struct Lstm4PackArgs {
+  const float* src[LSTM4_PACK_MAX];   // nullptr: slot left untouched (a path without a reverse direction)
+};
+__global__ __launch_bounds__(256) void lstm4_pack_kernel(Lstm4PackArgs a, float* __restrict__ dst) {
+  const float* W = a.src[blockIdx.y];
+  if (W == nullptr) return;
+  float4* out = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * (4 * L16_H * L16_H));
+  for (int f = blockIdx.x * 256 + threadIdx.x; f < L16_H * L16_H; f += gridDim.x * 256) {
+    const int lane = f & 63, q = (f >> 6) & 31, grp = (f >> 11) & 1, wv = f >> 12;
+    const int row = (2 * grp + (lane >> 5)) * L16_H + 32 * wv + (lane & 31);
+    out[f] = *reinterpret_cast<const float4*>(W + (size_t)row * L16_H + 4 * q);
+  }
+}
+int lstm4_pack_launch(void* stream, const float* const* src, int n, float* dst) {
+  if (n < 1 || n > LSTM4_PACK_MAX) return (int)hipErrorInvalidValue;
+  Lstm4PackArgs a;
+  for (int i = 0; i < LSTM4_PACK_MAX; ++i) a.src[i] = i < n ? src[i] : nullptr;
+  hipLaunchKernelGGL(lstm4_pack_kernel, dim3(16, n), dim3(256), 0, static_cast<hipStream_t>(stream), a, dst);
   return (int)hipGetLastError();
 }
