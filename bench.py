@@ -74,8 +74,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-PMC_TABLE = os.path.join(ROOT, "profiles", "r03_j_pmc_traffic.json")
-PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r03_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
+PMC_TABLES = {"dptn_av": os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"),
+              "dptn_audio": os.path.join(ROOT, "profiles", "r04_pmc_traffic_dptn_audio.json"),
+              "dprnn_av": os.path.join(ROOT, "profiles", "r04_pmc_traffic_dprnn_av.json")}
+PMC_TABLE = PMC_TABLES["dptn_av"]
+PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r04_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
 
 
 def pmc_table(config: str, path: str = None):
@@ -84,10 +87,22 @@ def pmc_table(config: str, path: str = None):
     at).  bench.py cannot read PMC counters itself, so `traffic` figures are FROM THIS FILE, for the configuration it was
     measured on only (anything else reports null)."""
     try:
-        d = json.load(open(path or PMC_TABLE))
+        d = json.load(open(path or PMC_TABLES.get(config, PMC_TABLE)))
         return d if d.get("config") == config else None
     except (OSError, ValueError):
         return None
+
+
+def table_state(tab) -> str:
+    """Whether a committed PMC table was taken with the kernels of THIS tree (its csrc_digest against build.source_digest())."""
+    from speech_separation_amd.build import source_digest
+    if not tab:
+        return "no table"
+    have = tab.get("csrc_digest")
+    if have is None:
+        return f"STALE? table of commit {tab.get('commit', '?')} predates the source digest: kernels may have changed since"
+    return "current (kernel sources unchanged since the table was taken)" if have == source_digest() else \
+        f"STALE: taken at commit {tab.get('commit', '?')} with other kernel sources (digest {have} != {source_digest()})"
 
 
 def log(msg: str):
@@ -158,6 +173,9 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+PROGRESS = {"phase": "-", "step": -1}      # what the N > 1 watchdog reports when a collective never returns
+
+
 def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
     """BASELINE configs[3] next to the headline: a few optimizer steps of the same model at batch 16 per GPU -- forward with
     tape, device PIT SI-SNR loss, HIP backward, device clip + AdamW, attention dropout 0.1 -- so that the driver-run line
@@ -178,8 +196,15 @@ def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
         seed = 123 + (env.rank if env is not None else 0)
         batch0 = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=seed).items()}
         crit = SiSNRWavLoss()
+        PROGRESS.update(phase="train_step: local set-up step", step=0)
         train_step(model, dict(batch0), crit, opt, 10.0)          # one local step (no collective): allocations, first launches
         torch.cuda.synchronize(dev)
+        if world > 1:
+            # that step used rank-specific data: put every replica back on the SAME weights and a fresh optimizer state, or
+            # the data-parallel steps below would average gradients of different models
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state_dict(model.cfg, seed=0).items()})
+            opt = FusedAdamW(model.parameters(), lr=1e-3)
+            torch.cuda.synchronize(dev)
     except Exception as e:      # noqa: BLE001
         ready, err = 0.0, e
     if world > 1 and env.sum_over_ranks([ready])[0] < world:
@@ -187,22 +212,47 @@ def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
     if err is not None:
         raise err
     ekw = {"env": env} if world > 1 else {}
-    for _ in range(warmup):
+    for i in range(warmup):
+        PROGRESS.update(phase="train_step: warm-up (gradient all-reduce inside)", step=i)
         train_step(model, dict(batch0), crit, opt, 10.0, **ekw)
     torch.cuda.synchronize(dev)
     if world > 1:
+        PROGRESS.update(phase="train_step: barrier before the timed steps", step=-1)
         env.barrier()
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        PROGRESS.update(phase="train_step: timed step (gradient all-reduce inside)", step=i)
         stats = train_step(model, dict(batch0), crit, opt, 10.0, **ekw)
     torch.cuda.synchronize(dev)
+    mine = time.perf_counter() - t0
     if world > 1:
+        PROGRESS.update(phase="train_step: barrier after the timed steps", step=-1)
         env.barrier()
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    per_rank_ms, allreduce = None, None
     if world > 1:
         dt = env.max_over_ranks(dt)
+        per_rank_ms = [round(1e3 * t / steps, 3) for t in env.gather_over_ranks(mine)]
+        # the collective's own device time: events around train.allreduce_gradients on the step's stream, after the timed
+        # region (same buffers, same 17.8 MB); every rank takes part, rank 0 reports max / min over ranks
+        from speech_separation_amd.train import allreduce_gradients
+        PROGRESS.update(phase="train_step: timing the gradient all-reduce alone", step=-1)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record()
+            how = allreduce_gradients(model, env)
+            b.record()
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+        all_ms = env.gather_over_ranks(ms)
+        nbytes = 4 * int(model._flat_grad.numel())
+        allreduce = {"how": how, "bytes": nbytes, "device_ms_median_max_over_ranks": round(max(all_ms), 4),
+                     "device_ms_median_min_over_ranks": round(min(all_ms), 4),
+                     "bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes / (max(all_ms) * 1e-3) / 1e9, 2),
+                     "note": "all_reduce(SUM) + div on the flat gradient tensor, HIP events on the step's stream; bus bandwidth = "
+                             "2 (n-1)/n x bytes / time (ring convention)"}
     dt /= steps
     flops = 3.0 * model._engine.flops_per_mixture(T) * B
     res = {"workload": f"configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), batch={B} per GPU, T={T}, dropout 0.1",
@@ -211,6 +261,10 @@ def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
            "parallelism": f"dp{world}" + (" (one flat 17.8 MB gradient all-reduce per step over RCCL, then clip + AdamW on every rank)" if world > 1 else ""),
            "note": "frac = 3 x forward FLOPs (612 GFLOP per mixture) / time / fp32-MFMA peak, per GPU; no host synchronisation in the step",
            "last_loss": round(float(stats["loss"]), 4)}
+    if world > 1:
+        res["per_rank_ms_per_step"] = per_rank_ms
+        res["per_rank_spread_ms"] = round(max(per_rank_ms) - min(per_rank_ms), 3)
+        res["gradient_allreduce"] = allreduce
     del model, opt, batch0
     torch.cuda.empty_cache()
     return res
@@ -367,6 +421,45 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
     return rows
 
 
+def profile_passes(eng, run_fn, psteps: int, psteps_alone: int):
+    """Per-kernel device time by HIP events on the launch stream (dptnav_profile_*), twice over the same workload:
+    as run (sub-batches on internal streams: up to three kernels share the chip, so a launch's duration is its SHARE of
+    the CUs, not its speed) and SERIALISED (option serialize: the very same sub-batch launches, one after the other on one
+    stream -- every launch alone on the chip; time the kernel actually owns)."""
+    eng.profile(True)
+    eng.profile_reset()
+    for _ in range(psteps):
+        run_fn()
+    prof = eng.profile_read()
+    eng.set_option("serialize", 1)
+    try:
+        eng.profile_reset()
+        for _ in range(psteps_alone):
+            run_fn()
+        prof_alone = eng.profile_read()
+    finally:
+        eng.set_option("serialize", 0)
+        eng.profile(False)
+    return prof, prof_alone
+
+
+def merged_rows(rows_run, rows_alone, table, B, T):
+    """One row per MFMA-bound class: the serialised (alone-on-the-chip) figures are `launch_ms` / `achieved` / `frac`, the
+    as-run ones sit under `as_run`; `traffic` from the committed PMC table when it covers this configuration and batch."""
+    by = {r["class"]: r for r in rows_run}
+    ok = table is not None and table.get("batch") == B and table.get("samples") == T
+    out = []
+    for r in rows_alone:
+        q = dict(r)
+        a = by.get(r["class"], {})
+        q["as_run"] = {k: a.get(k) for k in ("launch_ms", "ms_per_step", "achieved", "frac")}
+        krow = next((x for x in table["kernels"] if q.get("pmc_match") and q["pmc_match"] in x["name"]), None) if ok else None
+        q["traffic"] = krow["hbm_bytes_per_launch"] if krow else None
+        q.pop("pmc_match", None)
+        out.append(q)
+    return out, ok
+
+
 def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: int = 0):
     """A short, self-contained measurement of one forward configuration on this rank (N=1 legs of the headline line):
     mixtures/s, whole-path fraction of the fp32-MFMA peak and its dominant kernel's figures."""
@@ -387,21 +480,22 @@ def forward_leg(config: str, dev, steps: int, warmup: int, psteps: int, batch: i
         eng.forward(mix, e1, e2, out=out)
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    eng.profile(True)
-    eng.profile_reset()
-    for _ in range(psteps):
-        eng.forward(mix, e1, e2, out=out)
-    prof = eng.profile_read()
-    eng.profile(False)
-    rows = kernel_rows(cfg, eng, prof, psteps, B, T, dev)
+    prof, prof_alone = profile_passes(eng, lambda: eng.forward(mix, e1, e2, out=out), psteps, psteps)
+    tab = pmc_table(config)
+    rows, tab_ok = merged_rows(kernel_rows(cfg, eng, prof, psteps, B, T, dev), kernel_rows(cfg, eng, prof_alone, psteps, B, T, dev),
+                               tab, B, T)
     tf = B / dt * eng.flops_per_mixture(T) / 1e12
     res = {"workload": f"{workload}, batch={B}, T={T}", "value": round(B / dt, 3), "unit": "mixtures/sec",
            "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": warmup,
            "gflop_per_mixture": round(eng.flops_per_mixture(T) / 1e9, 1),
            "whole_path_tflops": round(tf, 2), "whole_path_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-           "dominant_kernel": {k: rows[0][k] for k in ("class", "kernel", "launches_per_step", "launch_ms", "ms_per_step", "achieved", "frac")
-                               if k in rows[0]} if rows else None,
-           "kernels": [{k: r[k] for k in ("class", "ms_per_step", "frac")} for r in rows],
+           "dominant_kernel": {k: rows[0][k] for k in ("class", "kernel", "launches_per_step", "launch_ms", "ms_per_step", "achieved", "frac",
+                                                       "as_run", "traffic") if k in rows[0]} if rows else None,
+           "kernels": [{"class": r["class"], "launch_ms": r["launch_ms"], "ms_per_step": r["ms_per_step"], "frac": r["frac"],
+                        "frac_as_run": r["as_run"]["frac"], "traffic": r["traffic"]} for r in rows],
+           "kernels_note": "launch_ms / ms_per_step / frac: the launch alone on the chip (serialised pass); frac_as_run: beside the "
+                           "other sub-batches' kernels",
+           "traffic_table": (os.path.relpath(PMC_TABLES[config], ROOT) + ": " + table_state(tab)) if tab_ok else None,
            "outputs_finite": bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())}
     del eng, out, mix, e1, e2
     torch.cuda.empty_cache()
@@ -515,6 +609,8 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision experiment leg")
     ap.add_argument("--pmc-run", action="store_true", help="warm-up + timed steps only (no per-kernel event pass, no isolated "
                     "pass, no CPU leg): the command rocprofv3 --pmc / --kernel-trace passes are taken over")
+    ap.add_argument("--serialize", action="store_true", help="with --pmc-run: option serialize = 1 (the step's sub-batch launches one "
+                    "after the other on one stream), the pass bench.py's roofline figures are taken from")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
@@ -548,6 +644,10 @@ def main():
     e1 = torch.from_numpy(inp["s1_embedding"]).to(dev) if not cfg.audio_only else None
     e2 = torch.from_numpy(inp["s2_embedding"]).to(dev) if not cfg.audio_only else None
     out = (torch.empty_like(mix), torch.empty_like(mix))
+    if args.serialize:
+        if not args.pmc_run:
+            raise SystemExit("--serialize is a profiling aid: use it with --pmc-run")
+        eng.set_option("serialize", 1)
 
     log(f"rank {env.rank}/{env.world} on {dev}: warm-up")
     for _ in range(args.warmup):
@@ -572,24 +672,9 @@ def main():
         return 0
 
     # ---- per-kernel device time: HIP events on the launch stream, same workload, separate pass ----------
-    eng.profile(True)
-    eng.profile_reset()
     psteps = max(1, min(args.steps, 10))
-    for _ in range(psteps):
-        eng.forward(mix, e1, e2, out=out)
-    prof = eng.profile_read()
-    # the recurrence once more with the two half-batches NOT overlapped (32-sequence-tile kernel alone on the chip)
-    eng.set_option("overlap", 0)
-    eng.profile_reset()
-    try:
-        for _ in range(3):
-            eng.forward(mix, e1, e2, out=out)
-        prof_iso = eng.profile_read()
-    except RuntimeError as e:   # e.g. a whole-batch launch exceeds the 32-bit token index range (DPRNN, B=32)
-        log(f"isolated pass skipped: {e}")
-        prof_iso = None
-    eng.set_option("overlap", 1)
-    eng.profile(False)
+    psteps_alone = max(1, min(args.steps, 5))
+    prof, prof_alone = profile_passes(eng, lambda: eng.forward(mix, e1, e2, out=out), psteps, psteps_alone)
     for _ in range(2):
         eng.forward(mix, e1, e2, out=out)          # `out` = the default (overlapped) path's result again
     finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())
@@ -601,32 +686,26 @@ def main():
     if env.rank == 0:
         S, K, H = eng.chunks(T), cfg.chunk_size, cfg.hidden_dim
         M = B * S * K
-        rows = kernel_rows(cfg, eng, prof, psteps, B, T, dev)
-        dom = rows[0]
-        # the same classes with the whole batch on ONE stream (option overlap=0): every kernel alone on the chip -- the as-run
-        # figures above are per launch with up to three kernels of different sub-batches in flight, which share the CUs
-        iso = None
-        if prof_iso is not None:
-            iso = [{k: r[k] for k in ("class", "kernel", "launches_per_step", "launch_ms", "achieved", "frac") if k in r}
-                   for r in kernel_rows(cfg, eng, prof_iso, 3, B, T, dev)[:3]]
-        kernels = {k: round(v[0] / psteps, 4) for k, v in prof.items()}
-        value = env.world * B * args.steps / elapsed
         # HBM traffic: from the committed PMC table (same configuration, batch and kernel only), never extrapolated
         tab = pmc_table(args.config)
-        tab_ok = tab is not None and tab.get("batch") == B and tab.get("samples") == T
+        # rows: one per MFMA-bound class, sorted by the device time the class OWNS per step (serialised pass: the same
+        # sub-batch launches alone on the chip); the as-run figures (launches of different sub-batches share the CUs) under `as_run`
+        rows, tab_ok = merged_rows(kernel_rows(cfg, eng, prof, psteps, B, T, dev),
+                                   kernel_rows(cfg, eng, prof_alone, psteps_alone, B, T, dev), tab, B, T)
+        dom = rows[0]
+        kernels = {k: round(v[0] / psteps, 4) for k, v in prof.items()}
+        kernels_alone = {k: round(v[0] / psteps_alone, 4) for k, v in prof_alone.items()}
+        value = env.world * B * args.steps / elapsed
         whole = None
-        for r in rows:
-            krow = next((x for x in tab["kernels"] if r.get("pmc_match") and r["pmc_match"] in x["name"]), None) if tab_ok else None
-            r["traffic"] = krow["hbm_bytes_per_launch"] if krow else None
-            r.pop("pmc_match", None)
-        traffic_unit = (f"HBM bytes per launch, from {os.path.relpath(PMC_TABLE, ROOT)} (PMC FETCH_SIZE x2 + WRITE_SIZE, commit "
-                        f"{tab.get('commit', '?')})") if tab_ok else f"no PMC table for this configuration / batch ({os.path.relpath(PMC_TABLE, ROOT)})"
+        tpath = os.path.relpath(PMC_TABLES.get(args.config, PMC_TABLE), ROOT)
+        traffic_unit = (f"HBM bytes per launch, from {tpath} (PMC FETCH_SIZE x2 + WRITE_SIZE; {table_state(tab)})") if tab_ok \
+            else f"no PMC table for this configuration / batch ({tpath})"
         if tab_ok:
             min_bytes = eng.min_bytes_per_mixture(T) * B
             whole = {"bytes_per_step": tab["bytes_per_step"], "bytes_per_mixture": round(tab["bytes_per_step"] / B),
                      "ideal_bytes_per_mixture": round(min_bytes / B), "ratio_to_ideal": round(tab["bytes_per_step"] / min_bytes, 2),
                      "avg_tb_per_s": round(tab["bytes_per_step"] / (elapsed / args.steps) / 1e12, 3),
-                     "source": f"{os.path.relpath(PMC_TABLE, ROOT)} (sum over kernels x launches per step, commit {tab.get('commit', '?')}; "
+                     "source": f"{tpath} (sum over kernels x launches per step; {table_state(tab)}; "
                                f"{tab.get('corrections', '')})"}
         line = {
             "metric": "mixtures/sec (2-spk, 4 s @ 8 kHz) DPTN-AV forward" if args.config == "dptn_av"
@@ -642,19 +721,26 @@ def main():
                          "traffic": dom["traffic"], "traffic_unit": traffic_unit,
                          "launch_ms": dom["launch_ms"], "flops_per_launch": dom["flops_per_launch"],
                          "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
-                         "dominant_by": "largest device time per step among the kernel classes of THIS run (kernels_ms_per_step)",
+                         "measured": "HIP events on the launch stream around every launch of the class, in a SERIALISED pass of the same "
+                                     "workload (option serialize: the step's own sub-batch launches, one after the other on one stream, "
+                                     "nothing else on the chip) -- the time the kernel owns.  rocprofv3 --kernel-trace --stats of "
+                                     "`bench.py --pmc-run --serialize` gives the same average (profiles/)",
+                         "as_run": dom["as_run"],
+                         "as_run_note": "the same launches inside the overlapped step: sub-batches run on separate streams and up to 3 "
+                                        "kernels share the CUs, so an as-run launch is longer than it is alone and its frac is a share "
+                                        "of the chip, not an efficiency (launches x as-run time may exceed the step)",
+                         "check": {"dominant_ms_per_step": dom["ms_per_step"], "step_ms": round(1e3 * elapsed / args.steps, 4),
+                                   "owns_less_than_the_step": bool(dom["ms_per_step"] <= 1e3 * elapsed / args.steps),
+                                   "sum_of_classes_ms_per_step_serialised": round(sum(kernels_alone.values()), 3)},
+                         "dominant_by": "largest device time per step among the kernel classes, serialised pass",
                          "kernels": rows,
-                         "kernels_in_flight": "sub-batches of the step run on separate streams: up to 3 kernels share the chip, so "
-                                              "a launch's duration (and `frac`) reflects its SHARE of the CUs; `isolated` = the same "
-                                              "kernels with nothing else on the chip (whole batch, one stream)",
-                         "isolated": iso,
-                         "frac_isolated": next((r["frac"] for r in (iso or []) if r["class"] == dom["class"]), None),
                          "whole_path_tflops": round(value / env.world * eng.flops_per_mixture(T) / 1e12, 3),
                          "whole_path_frac": round(value / env.world * eng.flops_per_mixture(T) / 1e12
                                                   / PEAK_F32_MFMA_TFLOPS, 4)},
             "whole_path_traffic": whole,
             "split_bf16_experiment": split,
             "kernels_ms_per_step": kernels,
+            "kernels_ms_per_step_serialised": kernels_alone,
             "outputs_finite": finite,
             "backend": env.backend, "rccl_ranks": env.backend_world() if env.backend == "nccl" else 0,
             "per_rank_mixtures_per_sec": [round(B * args.steps / t, 3) for t in per_rank_s],
@@ -667,11 +753,13 @@ def main():
         # the headline is measured; a collective that never returns in this optional leg must not cost it: after
         # DDP_LEG_LIMIT_S rank 0 prints the line without the leg and every rank leaves
         def give_up():
+            where = f"{PROGRESS['phase']}, step {PROGRESS['step']}"
             if env.rank == 0:
-                line["train_step"] = {"error": f"data-parallel training leg did not finish within {DDP_LEG_LIMIT_S} s; abandoned"}
+                line["train_step"] = {"error": f"data-parallel training leg did not finish within {DDP_LEG_LIMIT_S} s; abandoned "
+                                               f"(rank 0 outstanding in: {where}); process exit code 3"}
                 print(json.dumps(line), flush=True)
-            log(f"rank {env.rank}: training leg abandoned after {DDP_LEG_LIMIT_S} s")
-            os._exit(0)
+            log(f"rank {env.rank}: training leg abandoned after {DDP_LEG_LIMIT_S} s, outstanding in: {where}")
+            os._exit(3)      # the headline is printed, but a collective that never returned is NOT a clean run
         guard = threading.Timer(DDP_LEG_LIMIT_S, give_up)
         guard.daemon = True
         guard.start()

@@ -207,6 +207,9 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "overlap" (0/1, default 1): dptnav_forward runs the batch as two halves on two internal streams (forked from
  *                 and joined to the caller's stream by events) so that one half's GEMM/attention launches fill the
  *                 CUs the other half's LSTM recurrence cannot use; 0 = everything on the caller's stream.
+ *   "serialize" (0/1, default 0): a MEASUREMENT knob -- dptnav_forward keeps its sub-batch cut and kernel selection but enqueues
+ *                 every launch on the caller's stream, one after the other (no internal stream, no event): each launch is then
+ *                 alone on the chip, which is what bench.py's roofline figures time.  Results are bit-identical to 0.
  *   "dropout_ppm" (0..999999), "dropout_seed": train-mode dropout of the attention probabilities (dptn.py:16-21,
  *                 nn.MultiheadAttention(dropout=0.1)) for dptnav_train_forward/backward.  The keep-mask is a counter-based
  *                 hash of (seed, block, path, query token, head, key position): reproducible, identical in forward and

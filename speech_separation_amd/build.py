@@ -31,6 +31,18 @@ def _headers():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "dptnav.h")]
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: profiles record it, bench.py compares
+    it with the tree it runs from and says so when a committed PMC table was taken with other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(SOURCES) + _headers()):
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(OUT):
         return True

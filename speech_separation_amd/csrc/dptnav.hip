@@ -80,6 +80,7 @@ struct dptnav_ctx {
   bool prof_on = false;
   bool opt_lstm_stamps = false;
   bool opt_overlap = true;
+  bool opt_serialize = false;       // measurement: dptnav_forward keeps its sub-batch cut but enqueues every launch on the caller's stream
   bool opt_lstm16 = true;
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
@@ -969,8 +970,9 @@ struct BwdRun {
     side_slot += n;
     return q;
   }
-  unsigned* take_queue(int n) {
-    unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;
+  unsigned* take_queue(int n) {          // nullptr when the zeroed region is used up (the caller fails the launch): the
+    if (slot + n > QUEUE_SLOTS) return nullptr;   // backward recycles its counters per path while slot > QUEUE_SLOTS - 64, and a path takes
+    unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue) + slot;   // at most 40 (N = 128: 18 GEMMs + 6 wgrad; N = 64 / DPRNN: <= 40)
     slot += n;
     return q;
   }
@@ -992,6 +994,7 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
       ready.set(c->device_id);
     }
     unsigned* const queue = br.take_queue(1);
+    if (!queue) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, c->opt_deterministic ? nullptr : queue, yl, xl, slab, colslab);
   } else {
     auto kern = wgrad_kernel<NN, KK, YL, XL, false>;
@@ -1001,6 +1004,7 @@ int launch_wgrad(dptnav_ctx* c, BwdRun& br, const char* what, int64_t ntiles, co
       ready.set(c->device_id);
     }
     unsigned* const queue = br.take_queue(1);
+    if (!queue) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, br.st, (int)ntiles, c->opt_deterministic ? nullptr : queue, yl, xl, slab, (float*)nullptr);
   }
   LAUNCH_CHECK(c, what);
@@ -1351,6 +1355,13 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
     if (br.dg_sel) DG = br.ws + (br.dg_sel == 1 ? br.pl.dg2 : br.pl.dg3);
     if (br.wg_pending[br.dg_sel] && hipStreamWaitEvent(st, br.ev_wg[br.dg_sel], 0) != hipSuccess)
       return c->fail(DPTNAV_ERR_HIP, "side stream wait");
+  } else if (br.side != nullptr && br.wg_pending[0]) {
+    // A path whose weight gradients stay in this stream (one LSTM direction: bidir = False) writes its dP to buffer 0 --
+    // which a side-stream launch of an EARLIER path may still be reading.  Found by tests/test_gpu_memsafety.py (round 4):
+    // block 1's intra-chunk LSTM weight gradients of a bidir = False model came out wrong whenever the next (inter-chunk)
+    // BPTT overtook them.
+    if (hipStreamWaitEvent(st, br.ev_wg[0], 0) != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "side stream wait");
+    br.wg_pending[0] = false;
   }
   {
     ProfScope ps(c, CAT_LSTM, st);
@@ -1404,7 +1415,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         br.wg_pending[br.dg_sel] = true;
         br.dg_sel = (br.dg_sel + 1) % 3;
       } else {
-        if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, br.take_queue(4)))
+        unsigned* q4 = br.take_queue(4);
+        if (!q4) return c->fail(DPTNAV_ERR_INVALID, "d w_ih + d w_hh: ticket counters exhausted");
+        if (int rc = launch_wgrad2<256, N, 4>(c, br, "d w_ih + d w_hh", ntiles, wa, gA, gB, st, br.ws + br.pl.slab, q4))
           return rc;
       }
     }
@@ -1964,7 +1977,10 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
     return h->fail(DPTNAV_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need * sizeof(float));
   // sub-batches go round robin over min(nsub, NSTREAMS) internal streams (two for the default two halves)
   const int nstr = std::min(nsub, (int)dptnav_ctx::NSTREAMS);
-  if (nsub > 1) {
+  // option serialize: the same sub-batches and kernels, one after the other on the caller's stream (every launch alone on
+  // the chip: what bench.py's roofline times); no internal stream, no event
+  const bool forked = nsub > 1 && !h->opt_serialize;
+  if (forked) {
     if (int rc = h->ensure_streams()) return rc;
     if (int rc = h->ensure_sub_events(nsub)) return rc;
     if (hipEventRecord(h->ev_fork, st) != hipSuccess) return h->fail(DPTNAV_ERR_HIP, "fork event");
@@ -1981,7 +1997,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   auto enqueue = [&]() -> int {
   int64_t b0 = 0;
   for (int i = 0; i < nsub; ++i) {
-    hipStream_t si = nsub > 1 ? h->streams[i % nstr] : st;   // sub-batches go round robin over the internal streams
+    hipStream_t si = forked ? h->streams[i % nstr] : st;   // sub-batches go round robin over the internal streams
     if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
     mixi[i] = mix + b0 * T;
     e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
@@ -2014,7 +2030,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   for (int b = 0; b < g.num_blocks; ++b)
     for (int path = 0; path < 2; ++path)
       for (int i = 0; i < nsub; ++i, ++nlaunch) {
-        if (nsub > 1) {
+        if (forked) {
           run[i].lstm_wait = nlaunch >= depth && depth < nsub ? h->ev_sub[(nlaunch - depth) % nsub] : nullptr;
           run[i].lstm_record = h->ev_sub[i];
         }
@@ -2046,7 +2062,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   return DPTNAV_OK;
   };
   const int rc_body = enqueue();
-  return join_after(h, st, nsub > 1, rc_body, nstr);
+  return join_after(h, st, forked, rc_body, nstr);
 }
 
 int dptnav_workspace_tap(dptnav_handle h, int B, int64_t T, int Tv, const char* name, size_t* off, size_t* numel) {
@@ -2495,6 +2511,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "dropout_ppm" && value >= 0 && value < 1000000) h->opt_dropout_ppm = value;
   else if (k == "dropout_seed") h->opt_dropout_seed = (unsigned)value;
   else if (k == "overlap") h->opt_overlap = value != 0;
+  else if (k == "serialize") h->opt_serialize = value != 0;
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
   else if (k == "pack_whh") h->opt_pack_whh = value != 0;

@@ -49,9 +49,13 @@ class _DeviceBoundLib:
 class DptnEngine:
     """One handle <-> one device <-> the caller's current stream (include/dptnav.h threading contract)."""
 
-    def __init__(self, cfg: DPTNConfig, device: torch.device | str = "cuda:0"):
+    def __init__(self, cfg: DPTNConfig, device: torch.device | str = "cuda:0", alloc=None):
+        """`alloc(nbytes) -> uint8 device tensor, 256-byte aligned`: where the engine takes every buffer it allocates itself
+        from (workspaces, tapes, outputs, gradient buffers); default = the caching allocator.  The memory-safety tests
+        pass an allocator that places each buffer against an unmapped page (tests/guardmem)."""
         self.cfg = cfg
         self.device = torch.device(device)
+        self._alloc_hook = alloc
         if self.device.type != "cuda":
             raise RuntimeError("DptnEngine needs a GPU device (PyTorch-ROCm 'cuda:N'); there is no CPU path")
         if self.device.index is None:
@@ -93,6 +97,35 @@ class DptnEngine:
 
     def _raise(self, rc: int, what: str):
         raise RuntimeError(f"{what} failed ({rc}): {self.lib.dptnav_last_error(self._h).decode()}")
+
+    # ------------------------------------------------------------------ device memory
+    def _alloc(self, nbytes: int) -> torch.Tensor:
+        if self._alloc_hook is None:
+            return torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        t = self._alloc_hook(int(nbytes))
+        if t.dtype != torch.uint8 or t.device != self.device or t.numel() < nbytes or (nbytes and t.data_ptr() % 256):
+            raise ValueError("alloc hook must return a 256-byte aligned uint8 tensor of the requested size on the engine's device")
+        return t
+
+    def _empty(self, *shape) -> torch.Tensor:
+        if self._alloc_hook is None:
+            return torch.empty(*shape, device=self.device)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return self._alloc(4 * n)[:4 * n].view(torch.float32).view(*shape)
+
+    def _check_ws(self, ws: torch.Tensor, need: int, name: str = "ws") -> torch.Tensor:
+        """A caller-provided workspace: uint8, on this engine's device, 256-byte aligned, at least `need` bytes."""
+        if not isinstance(ws, torch.Tensor) or ws.dtype != torch.uint8:
+            raise TypeError(f"{name}: expected a uint8 tensor")
+        if ws.device != self.device:
+            raise ValueError(f"{name}: lives on {ws.device}, engine is on {self.device}")
+        if not ws.is_contiguous() or ws.data_ptr() % 256:
+            raise ValueError(f"{name}: must be contiguous and 256-byte aligned")
+        if ws.numel() < need:
+            raise ValueError(f"{name}: {ws.numel()} bytes, this call needs {need}")
+        return ws
 
     # ------------------------------------------------------------------ weights
     def bind(self, params: Mapping[str, torch.Tensor]):
@@ -136,7 +169,7 @@ class DptnEngine:
         need = self.workspace_bytes(B, T, Tv)
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = self._alloc(need)
         assert self._ws.data_ptr() % 256 == 0
         return self._ws
 
@@ -194,7 +227,14 @@ class DptnEngine:
             e1 = e2 = None
         if ws is None:
             ws = self._workspace(B, T, Tv)
-        s1, s2 = out if out is not None else (torch.empty_like(mix), torch.empty_like(mix))
+        else:
+            ws = self._check_ws(ws, self.workspace_bytes(B, T, Tv))
+        if out is not None:
+            s1, s2 = (_check(t, n, (B, T), self.device) for t, n in zip(out, ("out[0]", "out[1]")))
+            if s1.data_ptr() != out[0].data_ptr() or s2.data_ptr() != out[1].data_ptr():
+                raise ValueError("out: the output tensors must be contiguous")
+        else:
+            s1, s2 = self._empty(B, T), self._empty(B, T)
         rc = self.lib.dptnav_forward(self._h, mix.data_ptr(), _ptr(e1), _ptr(e2), B, T, Tv, s1.data_ptr(),
                                      s2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
         if rc:
@@ -202,18 +242,19 @@ class DptnEngine:
         return s1, s2
 
     # ------------------------------------------------------------------ training step, path level
-    def bind_grads(self) -> Dict[str, torch.Tensor]:
+    def bind_grads(self, per_slot: bool = False) -> Dict[str, torch.Tensor]:
         """Allocate the gradient buffers the library WRITES and bind them; returns {key: tensor}.  All of them are views
         of ONE flat tensor (`self._grads_flat`, every slot at a 256-byte aligned offset `self._grad_offsets[key]`), so
-        that a step can be handed to autograd with one copy and to RCCL with one collective."""
+        that a step can be handed to autograd with one copy and to RCCL with one collective.  per_slot = True (tests):
+        every slot is an allocation of its own, of exactly its size (no flat tensor; the C ABI takes any pointers)."""
         offs = self.flat_offsets()
-        flat = torch.zeros(self.flat_numel(), device=self.device)
+        flat = None if per_slot else self._empty(self.flat_numel()).zero_()
         grads, ptrs = {}, (C.c_void_p * len(self.slots))()
         for i, (key, shape) in enumerate(self.slots):
             n = 1
             for d in shape:
                 n *= int(d)
-            g = flat[offs[key]:offs[key] + n].view(*shape)
+            g = self._empty(*shape).zero_() if per_slot else flat[offs[key]:offs[key] + n].view(*shape)
             grads[key] = g
             ptrs[i] = g.data_ptr()
         rc = self.lib.dptnav_bind_grads(self._h, ptrs, len(self.slots))
@@ -233,7 +274,7 @@ class DptnEngine:
     def _tail_scratch(self, B: int) -> torch.Tensor:
         need = int(self.lib.dptnav_tail_scratch_bytes(self._h, max(B, 1)))
         if getattr(self, "_tail_ws", None) is None or self._tail_ws.numel() < need:
-            self._tail_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._tail_ws = self._alloc(need)
         return self._tail_ws
 
     def pit_sisnr_loss(self, s1_pred, s2_pred, s1, s2, grad_scale: float = 1.0):
@@ -242,8 +283,8 @@ class DptnEngine:
         B, T = s1_pred.shape
         ts = [_check(t.detach(), n, (B, T), self.device) for t, n in ((s1_pred, "s1_pred"), (s2_pred, "s2_pred"), (s1, "s1"),
                                                                      (s2, "s2"))]
-        d1, d2 = torch.empty_like(ts[0]), torch.empty_like(ts[1])
-        out = torch.empty(4, device=self.device)
+        d1, d2 = self._empty(B, T), self._empty(B, T)
+        out = self._empty(4)
         ws = self._tail_scratch(B)
         rc = self.lib.dptnav_pit_sisnr_loss(self._h, *[t.data_ptr() for t in ts], B, T, float(grad_scale), d1.data_ptr(),
                                             d2.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
@@ -254,7 +295,7 @@ class DptnEngine:
     def grad_clip(self, flat_grad: torch.Tensor, max_norm: Optional[float]) -> torch.Tensor:
         """Scales `flat_grad` (flat layout) in place like clip_grad_norm_; returns the pre-clip norm as a 0-dim device tensor."""
         flat_grad = _check(flat_grad, "flat_grad", (self.flat_numel(),), self.device)
-        norm = torch.empty(1, device=self.device)
+        norm = self._empty(1)
         ws = self._tail_scratch(1)
         rc = self.lib.dptnav_grad_clip(self._h, flat_grad.data_ptr(), flat_grad.numel(),
                                        float(max_norm) if max_norm is not None else 0.0, ws.data_ptr(), ws.numel(),
@@ -278,8 +319,8 @@ class DptnEngine:
         B, S, K, N = x.shape
         x = _check(x, "x", (B, S, self.cfg.chunk_size, self.cfg.num_features), self.device)
         ws = self._workspace(B, self._path_T(S), 1)
-        tape = torch.empty(int(self.lib.dptnav_train_path_tape_bytes(self._h, B, S)), dtype=torch.uint8, device=self.device)
-        y = torch.empty_like(x)
+        tape = self._alloc(int(self.lib.dptnav_train_path_tape_bytes(self._h, B, S)))
+        y = self._empty(*x.shape)
         rc = self.lib.dptnav_train_path_forward(self._h, block, path, x.data_ptr(), y.data_ptr(), B, S, tape.data_ptr(),
                                                 tape.numel(), ws.data_ptr(), ws.numel(), self._stream())
         if rc:
@@ -291,8 +332,9 @@ class DptnEngine:
         dy = _check(dy, "dy", tuple(x.shape), self.device)
         need = int(self.lib.dptnav_train_bwd_workspace_bytes(self._h, B, S))
         if getattr(self, "_bws", None) is None or self._bws.numel() < need:
-            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        dx = torch.empty_like(x)
+            self._bws = None
+            self._bws = self._alloc(need)
+        dx = self._empty(*x.shape)
         rc = self.lib.dptnav_train_path_backward(self._h, block, path, x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, S,
                                                  tape.data_ptr(), tape.numel(), self._bws.data_ptr(), self._bws.numel(),
                                                  self._stream())
@@ -304,7 +346,7 @@ class DptnEngine:
         """(nseq, heads, len, len) keep-mask of path (block, path) under the current dropout options (test helper)."""
         K = self.cfg.chunk_size
         nseq, ln = (B * S, K) if path == 0 else (B * K, S)
-        m = torch.empty(nseq, self.cfg.num_heads, ln, ln, device=self.device)
+        m = self._empty(nseq, self.cfg.num_heads, ln, ln)
         rc = self.lib.dptnav_dropout_mask(self._h, block, path, B, S, m.data_ptr(), self._stream())
         if rc:
             self._raise(rc, "dptnav_dropout_mask")
@@ -323,10 +365,11 @@ class DptnEngine:
         nw = int(self.lib.dptnav_train_workspace_bytes(self._h, B, T, Tv))
         if nt == 0 or nw == 0:
             raise RuntimeError(f"training step unsupported: {self.lib.dptnav_last_error(self._h).decode()}")
-        tape = torch.empty(nt, dtype=torch.uint8, device=self.device)
+        tape = self._alloc(nt)
         if getattr(self, "_tws", None) is None or self._tws.numel() < nw:
-            self._tws = torch.empty(nw, dtype=torch.uint8, device=self.device)
-        s1, s2 = torch.empty_like(mix), torch.empty_like(mix)
+            self._tws = None
+            self._tws = self._alloc(nw)
+        s1, s2 = self._empty(B, T), self._empty(B, T)
         rc = self.lib.dptnav_train_forward(self._h, mix.data_ptr(), _ptr(e1), _ptr(e2), B, T, Tv, s1.data_ptr(), s2.data_ptr(),
                                            tape.data_ptr(), tape.numel(), self._tws.data_ptr(), self._tws.numel(),
                                            self._stream())
@@ -352,7 +395,7 @@ class DptnEngine:
         B, T = mix.shape
         ts = [_check(t, n, (B, T), self.device) for t, n in ((s1_pred, "s1_pred"), (s2_pred, "s2_pred"), (s1, "s1"),
                                                              (s2, "s2"), (mix, "mix"))]
-        out = torch.empty(B, 6, 2, device=self.device)
+        out = self._empty(B, 6, 2)
         rc = self.lib.dptnav_sisnr_pairs(self._h, *[t.data_ptr() for t in ts], B, T, out.data_ptr(), self._stream())
         if rc:
             self._raise(rc, "dptnav_sisnr_pairs")
@@ -365,8 +408,8 @@ class DptnEngine:
         Tv = 1 if cfg.audio_only else e1.shape[-1]
         L, S = self.frames(T), self.chunks(T)
         ws = self._workspace(B, T, Tv)
-        enc = torch.empty(B, L, cfg.num_features, device=self.device)
-        chk = torch.empty(B, S, cfg.chunk_size, cfg.num_features, device=self.device)
+        enc = self._empty(B, L, cfg.num_features)
+        chk = self._empty(B, S, cfg.chunk_size, cfg.num_features)
         rc = self.lib.dptnav_stage_head(self._h, mix.contiguous().data_ptr(),
                                         _ptr(None if e1 is None else e1.contiguous()),
                                         _ptr(None if e2 is None else e2.contiguous()), B, T, Tv, enc.data_ptr(),
@@ -383,7 +426,7 @@ class DptnEngine:
         B, S, K, N = x.shape
         x = _check(x, "x", (B, S, self.cfg.chunk_size, self.cfg.num_features), self.device)
         ws = self._workspace(B, self._path_T(S), 1)
-        y = torch.empty_like(x)
+        y = self._empty(*x.shape)
         rc = self.lib.dptnav_stage_path(self._h, block, path, x.data_ptr(), y.data_ptr(), B, S, ws.data_ptr(),
                                         ws.numel(), self._stream())
         if rc:
@@ -393,8 +436,8 @@ class DptnEngine:
     def stage_tail(self, x: torch.Tensor, encoded: torch.Tensor, T: int):
         B = x.shape[0]
         ws = self._workspace(B, T, 1)
-        s1 = torch.empty(B, T, device=self.device)
-        s2 = torch.empty(B, T, device=self.device)
+        s1 = self._empty(B, T)
+        s2 = self._empty(B, T)
         rc = self.lib.dptnav_stage_tail(self._h, x.contiguous().data_ptr(), encoded.contiguous().data_ptr(), B, T,
                                         s1.data_ptr(), s2.data_ptr(), ws.data_ptr(), ws.numel(), self._stream())
         if rc:

@@ -79,13 +79,17 @@ def test_path_backward_matches_autograd(dev, path, features):
 
 
 @pytest.mark.parametrize("lstm_tile", [16, 32])     # both recurrence / BPTT kernel pairs
-@pytest.mark.parametrize("audio_only,features", [(False, 128), (True, 128), (True, 64)], ids=["av128", "audio128", "audio64"])
-def test_whole_model_backward_matches_autograd(dev, audio_only, features, lstm_tile):
+@pytest.mark.parametrize("audio_only,features,bidir", [(False, 128, True), (True, 128, True), (True, 64, True), (False, 128, False)],
+                         ids=["av128", "audio128", "audio64", "av128_unidir"])
+def test_whole_model_backward_matches_autograd(dev, audio_only, features, bidir, lstm_tile):
     """d loss / d every parameter for a 2-block model: libdptnav train_forward/backward vs torch.autograd (fp64, CPU).
-    audio64 = the reference's DPTNWavEncDec configuration (model/dptn_wav.yaml: 64 features)."""
+    audio64 = the reference's DPTNWavEncDec configuration (model/dptn_wav.yaml: 64 features); av128_unidir = bidir False
+    (dptn.py:60): its inter-chunk paths keep their LSTM weight gradients in the half's stream while the intra-chunk ones
+    go to the side stream (the dP buffer hand-over between the two was a race until round 4, tests/test_gpu_memsafety.py)."""
     from speech_separation_amd.engine import DptnEngine, params_to_device
     from speech_separation_amd.spec import synthetic_inputs
-    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0, "audio_only": audio_only, "num_features": features})
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 2, "dropout": 0.0, "audio_only": audio_only, "num_features": features,
+                        "bidir": bidir})
     sd = synthetic_state_dict(cfg, seed=2)
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(sd, dev))

@@ -32,6 +32,9 @@ ap.add_argument("--samples", type=int, default=32000)
 ap.add_argument("--command", default="python3 bench.py --pmc-run --steps 3 --warmup 1")
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_separation_amd.build import source_digest  # noqa: E402  (the tree the profiled command ran from)
 
 # kernels whose global reads are 16 B per lane (float4 / global_load_lds dwordx4) -- the gfx950 half-count applies to them
 WIDE_READERS = ("lstm16_kernel", "lstm16s_kernel", "lstm32s_kernel", "lstm_recurrence_kernel", "lstm_bptt", "gemm_ws_kernel", "attn_block",
@@ -63,7 +66,7 @@ for name, c in acc.items():
     total += (fetch + write) * per_step
 kernels.sort(key=lambda r: -r["hbm_bytes_per_step"])
 json.dump({"what": "HBM (L2 <-> fabric) bytes per kernel launch and per forward step, rocprofv3 PMC, kernels serialised by the "
-                   "counter pass", "commit": a.commit, "command": a.command, "config": a.config, "batch": a.batch,
+                   "counter pass", "commit": a.commit, "csrc_digest": source_digest(), "command": a.command, "config": a.config, "batch": a.batch,
            "samples": a.samples, "forwards_profiled": a.forwards,
            "corrections": "KiB -> bytes; FETCH_SIZE x2 for the kernels that read 16 B per lane / through LDS-DMA (gfx950 tallies those at "
                           "half; `wide_reads` per row), raw for the others; WRITE_SIZE exact",
