@@ -353,6 +353,8 @@ def class_flops_per_step(cfg, prof, B, S, L):
          "lstm_recurrence": sum(M * nb * nd * 2 * H * 4 * H for _, nd in paths),
          "sep_gemm": M * 2 * N * 2 * N, "postproc_gemm": float(B) * L * (2 * 2 * N * N + 2 * 2 * N * cfg.kernel_size_enc)}
     ffn = sum(M * nb * 2 * nd * H * N for _, nd in paths)
+    if prof["lstm_pre_gemm"][1] == 0:                      # input projection inside the recurrence (lstm16x.hip, 64 features)
+        f["lstm_recurrence"] += f.pop("lstm_pre_gemm")
     if cfg.arch != "dptn":
         f["ffn_ln_gemm"] = ffn                             # DPRNN: fc + LayerNorm + residual (dprnn.py:40-46)
         return f, False
@@ -398,10 +400,14 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
             wgs = sum(-(-int(b_launch * n_) // tile) * d for n_, d in ((S, 2), (K, ndir))) / 2.0     # mean of intra / inter
             occ = min(float(n_cus), wgs)
             kname = "lstm4_kernel" if fits4 else ("lstm16_kernel" if fits16 else "lstm_recurrence_kernel")
+            if prof["lstm_pre_gemm"][1] == 0:
+                tile, kname = 16, "lstm16x_kernel (x W_ih^T + b formed inside the recurrence: no K4 launch, no PRE tensor)"
+                wgs = sum(-(-int(b_launch * n_) // tile) * d for n_, d in ((S, 2), (K, ndir))) / 2.0
+                occ = min(float(n_cus), wgs)
             row.update(kernel=kname, pmc_match=kname,
                        workgroups_per_launch=round(wgs, 1), cus_occupied=round(occ, 1), rounds=round(wgs / n_cus, 2),
                        frac_of_occupied_cus=round(tf / (PEAK_F32_MFMA_TFLOPS * occ / n_cus), 4),
-                       algorithmic_bytes=int(B * S * K * 2 * cfg.num_blocks / lps) * (4 * cfg.hidden_dim * ndir + cfg.hidden_dim * ndir) * 4)
+                       algorithmic_bytes=int(B * S * K * 2 * cfg.num_blocks / lps) * ((cfg.num_features if prof["lstm_pre_gemm"][1] == 0 else 4 * cfg.hidden_dim * ndir) + cfg.hidden_dim * ndir) * 4)
         elif cls == "attention":
             fused = prof["qkv_gemm"][1] == 0
             row.update(kernel=("attn_block_kernel (in-proj + attention + out-proj + LN1" + (" + FFN/LN2 of the previous path)" if ffn_rides else ")"))

@@ -261,6 +261,11 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 a training step: a workgroup that starts late, beside another stream's kernel, keeps its share.
  *   "pack_wih" (0/1, default 1): the LSTM pre-activation GEMM reads W_ih from a fragment-order copy made at the start of
  *                 every pass (coalesced fragment loads in every workgroup's prologue); bit-identical to 0.
+ *   "fuse_pre" (0/1, default 1): num_features = 64, inference: the LSTM input projection x_t W_ih^T + b runs INSIDE the recurrence
+ *                 (lstm16x.hip: W_ih resident in LDS, 50 % more matrix work per step) instead of as a GEMM launch that writes
+ *                 the pre-activations to the workspace (2 KiB per token and direction, read again by the recurrence); launches
+ *                 small enough for the low-latency recurrence (lstm4) keep the GEMM.  Same sums in another order: results
+ *                 agree with 0 to fp32 rounding (> 110 dB).
  *   "pack_whh" (0/1, default 1): the low-latency recurrence (lstm4) reads W_hh from a fragment-order copy made at its
  *                 first launch of a pass; bit-identical to 0.
  *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a

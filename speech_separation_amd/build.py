@@ -24,7 +24,8 @@ SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "
            "attn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "attn_block64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm16s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-           "lstm4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+           "lstm4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "lstm16x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _headers():

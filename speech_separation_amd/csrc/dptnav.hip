@@ -82,6 +82,7 @@ struct dptnav_ctx {
   bool opt_overlap = true;
   bool opt_serialize = false;       // measurement: dptnav_forward keeps its sub-batch cut but enqueues every launch on the caller's stream
   bool opt_lstm16 = true;
+  bool opt_fuse_pre = true;         // num_features = 64, inference: the input projection runs INSIDE the recurrence (lstm16x.hip), no K4 launch, no PRE tensor
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
   bool opt_deterministic = false;   // 1: static tile assignment instead of device-wide tickets (TileTickets): bit-reproducible gradients
@@ -649,8 +650,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const int nst4 = (geom.nseq + 3) / 4;
   const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
                     (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= 23 * c->num_cus));
+  // num_features = 64: input projection inside the recurrence (lstm16x.hip) -- no K4 launch, no pre-activation tensor
+  const bool usex = N == 64 && c->opt_fuse_pre && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
-  {
+  if (!usex) {
     ALoadSeqTile al{lstm_in, N, geom};
     const int64_t nt4 = (int64_t)geom.nst * geom.len;
     int rc;
@@ -683,7 +686,12 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K5: recurrence, both directions concurrently; writes ReLU(h) (ffn[0], dptn.py:31)
   if (run.lstm_wait && hipStreamWaitEvent(st, run.lstm_wait, 0) != hipSuccess)
     return c->fail(DPTNAV_ERR_HIP, "lstm stagger wait");
-  if (use16 && split) {
+  if (usex) {
+    ProfScope ps(c, CAT_LSTM, st);
+    const int rc = lstm16x_launch(N, dptn, nst16, w.ndir, st, lstm_in, N, w.w_ih, w.b_ih, w.b_hh, w.w_hh, hc, w.ndir * LSTM_H,
+                                  M, geom);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16x: %s", hipGetErrorString((hipError_t)rc));
+  } else if (use16 && split) {
     ProfScope ps(c, CAT_LSTM, st);
     const int rc = lstm16s_launch(c->cfg.arch == 0, nst16, w.ndir, st, pre, w.w_hh[0], w.w_hh[1], hc, w.ndir * LSTM_H, (int)M, geom);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "lstm16s: %s", hipGetErrorString((hipError_t)rc));
@@ -2514,6 +2522,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "serialize") h->opt_serialize = value != 0;
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
+  else if (k == "fuse_pre") h->opt_fuse_pre = value != 0;
   else if (k == "pack_whh") h->opt_pack_whh = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {

@@ -56,3 +56,10 @@ int lstm4_launch(bool relu, int nst4, int nst16, int ndir, void* stream, const f
 // entries skipped) -> dst[n][512 * 128]
 constexpr int LSTM4_PACK_MAX = 24;
 int lstm4_pack_launch(void* stream, const float* const* src, int n, float* dst);
+
+// FUSED input projection (lstm16x.hip, num_features = 64): x_t W_ih^T + b is formed inside the recurrence (W_ih resident in
+// LDS), no pre-activation tensor in memory.  x: token-major [M][ldx]; wih / bih / bhh / whh: [direction] -> the nn.LSTM
+// tensors in their PyTorch layouts; hc addressed with 64-bit offsets (any launch size).  Inference only.
+int lstm16x_launch(int nin, bool relu, int nst16, int ndir, void* stream, const float* x, int ldx, const float* const* wih,
+                   const float* const* bih, const float* const* bhh, const float* const* whh, float* hc, int ldh,
+                   int64_t dump_row, const SeqGeom& g);

@@ -1,0 +1,273 @@
+// lstm16x.hip -- LSTM recurrence on 16-sequence tiles WITH the input projection inside (num_features = 64), gfx950.
+//
+// Reference semantics: torch.nn.LSTM(batch_first=True), gate order i, f, g, o (src/model/dptn.py:22-30,
+// src/model/dprnn.py:24-47):   gates_t = x_t W_ih^T + b_ih + h_{t-1} W_hh^T + b_hh.
+//
+// lstm16.hip takes `x_t W_ih^T + b` from HBM (PRE16, written by the K4 GEMM): 2 KiB per token and direction written and
+// read again -- for 64 features an 8x expansion of the 256-byte input row, and 80 % of a forward's HBM traffic.  Here the
+// pre-activations never exist in memory: one workgroup = one direction x 16 sequences x all positions keeps
+//   * W_hh (512 x 128) in the AGPR half of its register file, as lstm16.hip does, and
+//   * W_ih (512 x 64 = 128 KiB) in LDS, in MFMA B-fragment order (each wave its own 32 KiB: 8 blocks x 4 k-chunks),
+// reads the step's 16 x 64 input rows (4 KiB, one float4 per thread, requested three steps ahead) and accumulates
+//   acc = b + x_t W_ih^T  (128 MFMAs per wave, issued at the END of the previous step: they do not depend on h_{t-1})
+//   acc += h_{t-1} W_hh^T (256 MFMAs per wave)
+// in one chain.  The recurrence gets 50 % more matrix work per step; the K4 launch (as many FLOPs, plus 4 KiB of stores per
+// token) disappears.  Fragment maps, cell update and the h exchange are lstm16.hip's (v_mfma_f32_16x16x4_f32:
+// lane l: i16 = l & 15, ks = l >> 4; A[i16][ks], B[ks][i16], D reg r = (row 4ks + r, col i16); MFMA step 4m+t uses true
+// k = 16m + 4ks + t).  Compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py).
+#include <hip/hip_runtime.h>
+
+#include "lstm16.h"
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+static __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
+namespace {
+
+template <int NIN>
+struct X16 {
+  static constexpr int MK = NIN / 16;                   // k-chunks of the input projection
+  static constexpr int LDX = NIN + 8;                   // input rows in LDS: conflict-free ds_read_b128 for the 16x16x4 A map
+  static constexpr int WL_FLOATS = 4 * MK * 8 * 256;    // [wave][m][block][lane][4]
+  static constexpr int XS_FLOATS = 2 * 16 * LDX;        // two steps of input rows
+  static constexpr int NXL = (16 * NIN / 4) / 256;      // float4 of an input tile per thread
+  static constexpr size_t LDS_BYTES = sizeof(float) * (WL_FLOATS + L16_HS_FLOATS + XS_FLOATS);
+  static_assert((16 * NIN / 4) % 256 == 0 && NIN % 16 == 0, "input tile / threads");
+  static_assert(LDS_BYTES <= 160 * 1024, "W_ih must fit the LDS beside the h and x tiles");
+};
+
+template <int NIN, bool RELU>
+__global__ __launch_bounds__(256) void lstm16x_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wih_f,
+                                                       const float* __restrict__ wih_b, const float* __restrict__ bih_f,
+                                                       const float* __restrict__ bih_b, const float* __restrict__ bhh_f,
+                                                       const float* __restrict__ bhh_b, const float* __restrict__ whh_f,
+                                                       const float* __restrict__ whh_b, float* __restrict__ hc, int ldh,
+                                                       int64_t dump_row, SeqGeom g) {
+  using Sh = X16<NIN>;
+  constexpr int MK = Sh::MK, LDX = Sh::LDX, NXL = Sh::NXL;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                               // [4][MK][8][256]
+  float* Hs = smem + Sh::WL_FLOATS;               // [2][16][L16_LDH]
+  float* Xs = Hs + L16_HS_FLOATS;                 // [2][16][LDX]
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, i16 = lane & 15, ks = lane >> 4;
+  const int st = blockIdx.x, d = blockIdx.y;
+  const float* whh = d ? whh_b : whh_f;
+  const float* wih = d ? wih_b : wih_f;
+  const float* bih = d ? bih_b : bih_f;
+  const float* bhh = d ? bhh_b : bhh_f;
+
+  // ---- W_hh -> AGPRs (B fragments of the recurrent product), pre-scaled for the exp2 forms of sigmoid / tanh ----------
+  float wf[8][32];
+  float bsc[8];                                   // (b_ih + b_hh) of the lane's column in block b, pre-scaled
+  float* wl_wave = Wl + w * (MK * 8 * 256) + lane * 4;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int row = (b >> 1) * L16_H + 32 * w + 16 * (b & 1) + i16;
+    const float gs = l16_gate_scale(b >> 1);
+    const float* wrow = whh + (int64_t)row * L16_H + 4 * ks;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 16 * m);
+      wf[b][4 * m + 0] = v.x * gs;
+      wf[b][4 * m + 1] = v.y * gs;
+      wf[b][4 * m + 2] = v.z * gs;
+      wf[b][4 * m + 3] = v.w * gs;
+    }
+    bsc[b] = (bih[row] + bhh[row]) * gs;
+    // ---- W_ih -> LDS, the same fragment map (this lane writes exactly what it will read) ----------------------------------
+    const float* irow = wih + (int64_t)row * NIN + 4 * ks;
+#pragma unroll
+    for (int m = 0; m < MK; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(irow + 16 * m);
+      *reinterpret_cast<float4*>(wl_wave + (m * 8 + b) * 256) = make_float4(v.x * gs, v.y * gs, v.z * gs, v.w * gs);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+a"(wf[b][i]));
+
+  const int t0 = d ? g.len - 1 : 0, tdir = d ? -1 : 1;
+  const int tstride = seq_token_stride(g);
+  // ---- h rows leave through the LDS tile (lstm16.hip): wave w stores tile rows 4w + 2j + (lane >> 5), 16 bytes at column
+  // 4 (lane & 31).  Rows of padded sequences walk through the dump rows.  64-bit addresses: a DPRNN launch of 16 mixtures
+  // x 8 s is 4 M tokens x 1 KiB.
+  const int srow = 4 * w + (lane >> 5), scol = 4 * (lane & 31);
+  char* hp[2];
+  const int64_t hstep = (int64_t)tdir * tstride * ldh * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = st * 16 + srow + 2 * j;
+    const int64_t tokb = q < g.nseq ? seq_token_base(g, q) : dump_row;
+    hp[j] = reinterpret_cast<char*>(hc) + ((tokb + (int64_t)t0 * tstride) * ldh + d * L16_H + scol) * 4;
+  }
+  // ---- input rows: thread -> (row, 16-byte chunk) of the 16 x NIN tile; padded sequences read the last real one ------------
+  const char* xp[NXL];
+  int xoff[NXL];                                  // float offset inside an Xs buffer
+  const int64_t xstep = (int64_t)tdir * tstride * ldx * 4;
+#pragma unroll
+  for (int i = 0; i < NXL; ++i) {
+    const int idx = i * 256 + tid, row = idx / (NIN / 4), ch = idx % (NIN / 4);
+    const int q = st * 16 + row;
+    const int64_t tokb = seq_token_base(g, q < g.nseq ? q : g.nseq - 1);
+    xp[i] = reinterpret_cast<const char*>(x) + ((tokb + (int64_t)t0 * tstride) * ldx + 4 * ch) * 4;
+    xoff[i] = row * LDX + 4 * ch;
+  }
+  float4 xr[NXL];
+  // x_0 -> Xs[0], x_1 -> Xs[1], x_2 -> registers (positions past the end re-read the last one: never used)
+  auto load_x = [&](int s) {
+    const int64_t adv = (int64_t)(s < g.len ? s : g.len - 1) * xstep;
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) xr[i] = *reinterpret_cast<const float4*>(xp[i] + adv);
+  };
+  auto stage_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) *reinterpret_cast<float4*>(Xs + buf * 16 * LDX + xoff[i]) = xr[i];
+  };
+  load_x(0);
+  stage_x(0);
+  load_x(1);
+  stage_x(1);
+  load_x(2);
+  for (int i = tid; i < 16 * L16_LDH; i += 256) Hs[i] = 0.f;      // h_{-1} = 0 (buffer 0)
+  f32x4v cst[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
+  __syncthreads();
+
+  // ---- acc = b + x W_ih^T of one step, from the staged rows (all of a wave's B fragments come from its own LDS slice) -----
+  f32x4v acc[8];
+  auto input_part = [&](int buf) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = (f32x4v){bsc[b], bsc[b], bsc[b], bsc[b]};
+    const float* xrow = Xs + buf * 16 * LDX + i16 * LDX + 4 * ks;
+    float4 xa[MK];
+#pragma unroll
+    for (int m = 0; m < MK; ++m) xa[m] = *reinterpret_cast<const float4*>(xrow + 16 * m);
+    float4 wcur[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) wcur[b] = *reinterpret_cast<const float4*>(wl_wave + b * 256);
+#pragma unroll
+    for (int m = 0; m < MK; ++m) {
+      float4 wnext[8];
+      if (m + 1 < MK) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) wnext[b] = *reinterpret_cast<const float4*>(wl_wave + ((m + 1) * 8 + b) * 256);
+      }
+      const float av[4] = {xa[m].x, xa[m].y, xa[m].z, xa[m].w};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const float bv[4] = {wcur[b].x, wcur[b].y, wcur[b].z, wcur[b].w};
+          acc[b] = mfma16(av[tt], bv[tt], acc[b]);
+        }
+      }
+      if (m + 1 < MK) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) wcur[b] = wnext[b];
+      }
+    }
+  };
+  input_part(0);
+  __syncthreads();      // step 0 overwrites the buffer of x_0 with x_2
+
+  for (int step = 0; step < g.len; ++step) {
+    const float* hcur = Hs + (step & 1) * 16 * L16_LDH;
+    float* hnext = Hs + ((step + 1) & 1) * 16 * L16_LDH;
+    const float* arow = hcur + i16 * L16_LDH + 4 * ks;
+    float4 afr[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) afr[m] = *reinterpret_cast<const float4*>(arow + 16 * m);
+    float4 hs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
+    // step 0 stores the zeros of h_{-1} at position t0 without advancing and step 1 overwrites them
+    const int64_t adv = step > 0 ? hstep : 0;
+
+    auto cell_half = [&](int hf) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const LstmCell2 u = lstm_cell2((f32x2){acc[hf][r], acc[hf][r + 1]}, (f32x2){acc[2 + hf][r], acc[2 + hf][r + 1]},
+                                       (f32x2){acc[4 + hf][r], acc[4 + hf][r + 1]}, (f32x2){acc[6 + hf][r], acc[6 + hf][r + 1]},
+                                       (f32x2){cst[hf][r], cst[hf][r + 1]});
+        cst[hf][r] = u.c.x;
+        cst[hf][r + 1] = u.c.y;
+        hnext[(4 * ks + r) * L16_LDH + 32 * w + 16 * hf + i16] = u.h.x;
+        hnext[(4 * ks + r + 1) * L16_LDH + 32 * w + 16 * hf + i16] = u.h.y;
+      }
+    };
+
+    // h_{t-1} W_hh^T, unit half by unit half (lstm16.hip); one memory instruction per MFMA group in the first groups:
+    // slots 0, 1 the stores of h_{t-1}; then the input rows of step + 2 go from registers to LDS (they are read at the end of
+    // step + 1, behind the barrier that closes this step) and the rows of step + 3 are requested
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float av[4] = {afr[m].x, afr[m].y, afr[m].z, afr[m].w};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+          for (int gt = 0; gt < 4; ++gt) acc[2 * gt + hf] = mfma16(av[tt], wf[2 * gt + hf][4 * m + tt], acc[2 * gt + hf]);
+          const int slot = 4 * m + tt;
+          if (hf == 0 && slot < 2) {
+            asm volatile("" : "+v"(hs[slot].x), "+v"(hs[slot].y), "+v"(hs[slot].z), "+v"(hs[slot].w));
+            if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
+            *reinterpret_cast<float4*>(hp[slot]) = hs[slot];
+            hp[slot] += adv;
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (hf == 0 && slot == 2) {
+            stage_x(step & 1);                    // x_{step+2}: buffer of x_step, last read before the previous barrier
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (hf == 0 && slot == 3) {
+            load_x(step + 3);
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (hf == 1) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+          }
+        }
+      }
+      if (hf == 0) cell_half(0);
+    }
+    cell_half(1);
+    // the next step's input part: independent of h_t, so it runs in front of the barrier the wave would otherwise wait at
+    if (step + 1 < g.len) input_part((step + 1) & 1);
+    __syncthreads();
+  }
+  // h of the last step: the barrier above published it in buffer (len & 1)
+  {
+    const float* hfin = Hs + (g.len & 1) * 16 * L16_LDH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 v = *reinterpret_cast<const float4*>(hfin + (srow + 2 * j) * L16_LDH + scol);
+      if (RELU) v = make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w));
+      *reinterpret_cast<float4*>(hp[j]) = v;
+    }
+  }
+}
+
+}  // namespace
+
+int lstm16x_launch(int nin, bool relu, int nst16, int ndir, void* stream, const float* x, int ldx, const float* const* wih,
+                   const float* const* bih, const float* const* bhh, const float* const* whh, float* hc, int ldh,
+                   int64_t dump_row, const SeqGeom& g) {
+  if (nin != 64 || nst16 < 1 || ndir < 1 || ndir > 2 || g.len < 1) return (int)hipErrorInvalidValue;
+  auto kern = relu ? lstm16x_kernel<64, true> : lstm16x_kernel<64, false>;
+  constexpr size_t lds = X16<64>::LDS_BYTES;
+  static PerDeviceOnce ready[2];
+  const int dev = current_hip_device();
+  if (!ready[relu].done(dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    ready[relu].set(dev);
+  }
+  const int r = ndir == 2 ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(nst16, ndir), dim3(256), lds, static_cast<hipStream_t>(stream), x, ldx, wih[0], wih[r], bih[0],
+                     bih[r], bhh[0], bhh[r], whh[0], whh[r], hc, ldh, dump_row, g);
+  return (int)hipGetLastError();
+}

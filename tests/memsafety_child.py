@@ -45,8 +45,11 @@ VARIANTS = {
     "dptn128_long": (_cfg(DPTN_AV, num_blocks=1), {}, 2, 48000, 50, 1),          # inter-chunk sequences > 160: streaming attention
     "dptn64": (_cfg(DPTN_AUDIO, num_blocks=2), {}, 5, 8000, 1, 3),
     "dptn64_lstm4": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 2}, 3, 5000, 1, 2),
+    "dptn64_lstm16x": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 0}, 5, 8000, 1, 3),          # input projection inside the recurrence
+    "dptn64_pre": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 0, "fuse_pre": 0}, 3, 5000, 1, 0),  # ... and the K4 + lstm16 path
     "dprnn": (_cfg(DPRNN_AV, num_blocks=2), {}, 3, 4000, 9, 2),
     "dprnn_lstm32": (_cfg(DPRNN_AV, num_blocks=2), {"lstm16": 0, "lstm4": 0}, 3, 4000, 9, 2),
+    "dprnn_lstm16x": (_cfg(DPRNN_AV, num_blocks=2), {"lstm4": 0}, 3, 4000, 9, 0),
     "unidir128": (_cfg(DPTN_AV, num_blocks=2, bidir=False), {}, 5, 8000, 13, 3),
     "unidir64": (_cfg(DPTN_AUDIO, num_blocks=2, bidir=False), {}, 4, 8000, 1, 2),
     "split_bf16": (_cfg(DPTN_AV, num_blocks=2), {"split_bf16": 1}, 5, 8000, 13, 0),

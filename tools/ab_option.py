@@ -1,6 +1,7 @@
 """Same-box A/B of an engine option (boxes differ by 1-2 %, so two builds / settings are only comparable inside one process):
 forward at B = 16 and bs = 1, DPTN-AV and DPTN audio-only, alternating the option's values.
-usage: ab_option.py <option> <value_a> <value_b> [rounds]"""
+usage: ab_option.py <option> <value_a> <value_b> [rounds] [configs]      configs: comma-separated among dptn_av, dptn_audio,
+dprnn_av (B = 32 x 128000 samples, BASELINE configs[4]); default dptn_av,dptn_audio"""
 import os
 import sys
 import time
@@ -13,16 +14,20 @@ if os.environ.get("AB_LIB"):          # A/B of two BUILDS: AB_LIB=<path to the o
     import speech_separation_amd._lib as _L
     _L.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
 from speech_separation_amd.engine import DptnEngine, params_to_device  # noqa: E402
-from speech_separation_amd.spec import DPTN_AUDIO, DPTN_AV, synthetic_inputs, synthetic_state_dict  # noqa: E402
+from speech_separation_amd.spec import DPRNN_AV, DPTN_AUDIO, DPTN_AV, synthetic_inputs, synthetic_state_dict  # noqa: E402
 
 opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 dev = torch.device("cuda:0")
-for name, cfg in (("dptn_av", DPTN_AV), ("dptn_audio", DPTN_AUDIO)):
+ALL = {"dptn_av": (DPTN_AV, 32000, ((16, 20), (1, 40))), "dptn_audio": (DPTN_AUDIO, 32000, ((16, 20), (1, 40))),
+       "dprnn_av": (DPRNN_AV, 128000, ((32, 3),))}
+names = sys.argv[5].split(",") if len(sys.argv) > 5 else ["dptn_av", "dptn_audio"]
+for name in names:
+    cfg, T, sizes = ALL[name]
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
-    for B, reps in ((16, 20), (1, 40)):
-        t = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=32000, Tv=50, seed=1).items()}
+    for B, reps in sizes:
+        t = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=1).items()}
         args = (t["mix"], t.get("s1_embedding"), t.get("s2_embedding"))
         res = {va: [], vb: []}
         for r in range(rounds):
