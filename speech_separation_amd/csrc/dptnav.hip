@@ -82,6 +82,7 @@ struct dptnav_ctx {
   bool opt_overlap = true;
   bool opt_serialize = false;       // measurement: dptnav_forward keeps its sub-batch cut but enqueues every launch on the caller's stream
   bool opt_lstm16 = true;
+  bool opt_fuse_pre128 = false;     // the same for num_features = 128 (lstm16x128_kernel: W_ih split between LDS and VGPRs)
   bool opt_fuse_pre = true;         // num_features = 64, inference: the input projection runs INSIDE the recurrence (lstm16x.hip), no K4 launch, no PRE tensor
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
@@ -651,7 +652,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
                     (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= 23 * c->num_cus));
   // num_features = 64: input projection inside the recurrence (lstm16x.hip) -- no K4 launch, no pre-activation tensor
-  const bool usex = N == 64 && c->opt_fuse_pre && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
+  const bool usex = (N == 64 ? c->opt_fuse_pre : c->opt_fuse_pre128) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   if (!usex) {
     ALoadSeqTile al{lstm_in, N, geom};
@@ -2523,6 +2524,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
   else if (k == "fuse_pre") h->opt_fuse_pre = value != 0;
+  else if (k == "fuse_pre128") h->opt_fuse_pre128 = value != 0;
   else if (k == "pack_whh") h->opt_pack_whh = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {

@@ -251,20 +251,252 @@ __global__ __launch_bounds__(256) void lstm16x_kernel(const float* __restrict__ 
   }
 }
 
+// =====================================================================================================================
+// num_features = 128: W_ih (512 x 128) is as large as W_hh and the two do not fit one CU's registers together -- W_hh fills
+// the AGPR half (256 registers per lane), the LDS has room for 31 of the wave's 64 W_ih fragment sets (k-chunk m, block b)
+// beside the h and x tiles, and the other 33 sets (132 registers) live in the architectural VGPRs.  That leaves ~120
+// registers for everything else, so the step is written for short live ranges: the recurrent product walks the k-chunks with
+// both unit halves per chunk (one h fragment live at a time; the cell update of both halves follows the last MFMA), and the
+// input part takes its LDS fragments in groups of four sets, one group ahead.
+constexpr int X128_RES = 33;                                   // fragment sets p = 8 m + b < X128_RES: registers; others: LDS
+constexpr int X128_WL_FLOATS = 4 * (64 - X128_RES) * 256;      // [wave][set - RES][lane][4]
+constexpr int X128_XS_FLOATS = 16 * 128;                       // one step's input rows, unpadded (LDS-DMA), 16-byte chunks XOR-swizzled
+constexpr size_t X128_LDS_BYTES = sizeof(float) * (X128_WL_FLOATS + L16_HS_FLOATS + 2 * X128_XS_FLOATS);
+static_assert(X128_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wih_f,
+                                                          const float* __restrict__ wih_b, const float* __restrict__ bih_f,
+                                                          const float* __restrict__ bih_b, const float* __restrict__ bhh_f,
+                                                          const float* __restrict__ bhh_b, const float* __restrict__ whh_f,
+                                                          const float* __restrict__ whh_b, float* __restrict__ hc, int ldh,
+                                                          int64_t dump_row, SeqGeom g) {
+  constexpr int NIN = 128, RES = X128_RES;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                               // [4][64 - RES][256]
+  float* Hs = smem + X128_WL_FLOATS;              // [2][16][L16_LDH]
+  float* Xs = Hs + L16_HS_FLOATS;                 // [2][16][128], chunk c of row r stored at chunk position c ^ (r & 15)
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, i16 = lane & 15, ks = lane >> 4;
+  const int st = blockIdx.x, d = blockIdx.y;
+  const float* whh = d ? whh_b : whh_f;
+  const float* wih = d ? wih_b : wih_f;
+  const float* bih = d ? bih_b : bih_f;
+  const float* bhh = d ? bhh_b : bhh_f;
+
+  float wf[8][32];                                // W_hh fragments -> AGPRs
+  float bsc[8];
+  float* wl_wave = Wl + w * ((64 - RES) * 256) + lane * 4;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int row = (b >> 1) * L16_H + 32 * w + 16 * (b & 1) + i16;
+    const float gs = l16_gate_scale(b >> 1);
+    const float* wrow = whh + (int64_t)row * L16_H + 4 * ks;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 16 * m);
+      wf[b][4 * m + 0] = v.x * gs;
+      wf[b][4 * m + 1] = v.y * gs;
+      wf[b][4 * m + 2] = v.z * gs;
+      wf[b][4 * m + 3] = v.w * gs;
+    }
+    bsc[b] = (bih[row] + bhh[row]) * gs;
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) asm volatile("" : "+a"(wf[b][i]));
+  float wiv[RES][4];                              // W_ih fragment sets 0 .. RES-1 -> VGPRs, the others -> LDS
+#pragma unroll
+  for (int p = 0; p < 64; ++p) {
+    const int m = p >> 3, b = p & 7;
+    const int row = (b >> 1) * L16_H + 32 * w + 16 * (b & 1) + i16;
+    const float gs = l16_gate_scale(b >> 1);
+    const float4 v = *reinterpret_cast<const float4*>(wih + (int64_t)row * NIN + 16 * m + 4 * ks);
+    if (p < RES) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      wiv[p % RES][0] = v.x * gs;
+      wiv[p % RES][1] = v.y * gs;
+      wiv[p % RES][2] = v.z * gs;
+      wiv[p % RES][3] = v.w * gs;
+    } else {
+      *reinterpret_cast<float4*>(wl_wave + (p - RES) * 256) = make_float4(v.x * gs, v.y * gs, v.z * gs, v.w * gs);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < RES; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wiv[p][i]));
+
+  const int t0 = d ? g.len - 1 : 0, tdir = d ? -1 : 1;
+  const int tstride = seq_token_stride(g);
+  const int srow = 4 * w + (lane >> 5), scol = 4 * (lane & 31);
+  char* hp[2];
+  const int64_t hstep = (int64_t)tdir * tstride * ldh * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = st * 16 + srow + 2 * j;
+    const int64_t tokb = q < g.nseq ? seq_token_base(g, q) : dump_row;
+    hp[j] = reinterpret_cast<char*>(hc) + ((tokb + (int64_t)t0 * tstride) * ldh + d * L16_H + scol) * 4;
+  }
+  // input rows: 16 x 512 bytes per step, by LDS-DMA (no registers): wave w issues two 1-KiB requests, request j = 2w + i covers
+  // rows 2j and 2j + 1 -- lane L delivers 16 bytes to LDS position 16 L of the request's KiB, so it FETCHES the chunk that
+  // belongs there: row 2j + (L >> 5), chunk (L & 31) ^ (row & 15) (the XOR spreads a fragment read's 16 rows over the banks).
+  // Padded sequences read the last real one.
+  const char* xp[2];
+  const int64_t xstep = (int64_t)tdir * tstride * ldx * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 2 * (2 * w + i) + (lane >> 5);
+    const int q = st * 16 + row;
+    const int64_t tokb = seq_token_base(g, q < g.nseq ? q : g.nseq - 1);
+    xp[i] = reinterpret_cast<const char*>(x) + ((tokb + (int64_t)t0 * tstride) * ldx + 4 * ((lane & 31) ^ (row & 15))) * 4;
+  }
+  auto dma_x = [&](int s, int buf, int i) {        // x_s -> Xs[buf], this wave's request i
+    const int64_t adv = (int64_t)(s < g.len ? s : g.len - 1) * xstep;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + adv),
+                                     (__attribute__((address_space(3))) void*)(Xs + buf * X128_XS_FLOATS + (2 * w + i) * 256), 16, 0, 0);
+  };
+  dma_x(0, 0, 0); dma_x(0, 0, 1);
+  dma_x(1, 1, 0); dma_x(1, 1, 1);
+  for (int i = tid; i < 16 * L16_LDH; i += 256) Hs[i] = 0.f;
+  f32x4v cst[2] = {(f32x4v){0.f, 0.f, 0.f, 0.f}, (f32x4v){0.f, 0.f, 0.f, 0.f}};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4v acc[8];
+  // the lane's A fragment of k-chunk m: chunk 4m + ks of row i16, at chunk position (4m + ks) ^ i16 = 4 (m ^ (i16 >> 2)) + (ks ^ (i16 & 3))
+  const int xlane = i16 * 128 + 4 * (ks ^ (i16 & 3));
+  const int xq = i16 >> 2;
+  // acc = b + x W_ih^T: 16 groups of four fragment sets (k-chunk m = group / 2, blocks 4 (group & 1) .. + 3); the sets that live
+  // in LDS are fetched one group ahead into a ping-pong pair of four float4
+  auto input_part = [&](int buf) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = (f32x4v){bsc[b], bsc[b], bsc[b], bsc[b]};
+    const float* xrow = Xs + buf * X128_XS_FLOATS + xlane;
+    float4 fb[2][4];
+    float4 xa = *reinterpret_cast<const float4*>(xrow + 16 * (0 ^ xq));
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float4 xa_next = xa;
+      if (m + 1 < 8) xa_next = *reinterpret_cast<const float4*>(xrow + 16 * (((m + 1) & 3) ^ xq) + 64 * ((m + 1) >> 2));
+      const float av[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int gi = 2 * m + half;
+        if (gi + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int p = 4 * (gi + 1) + j;
+            if (p >= RES) fb[(gi + 1) & 1][j] = *reinterpret_cast<const float4*>(wl_wave + (p - RES) * 256);
+          }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int p = 4 * gi + j, b = p & 7;
+            float bv;
+            if (p < RES) {
+              bv = wiv[p % RES][tt];
+            } else {
+              const float4 f = fb[gi & 1][j];
+              bv = tt == 0 ? f.x : (tt == 1 ? f.y : (tt == 2 ? f.z : f.w));
+            }
+            acc[b] = mfma16(av[tt], bv, acc[b]);
+          }
+        }
+      }
+      xa = xa_next;
+    }
+  };
+  input_part(0);
+  __syncthreads();      // step 0 requests x_2 into the buffer of x_0
+
+  for (int step = 0; step < g.len; ++step) {
+    const float* hcur = Hs + (step & 1) * 16 * L16_LDH;
+    float* hnext = Hs + ((step + 1) & 1) * 16 * L16_LDH;
+    const float* arow = hcur + i16 * L16_LDH + 4 * ks;
+    float4 hs[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
+    float4 a = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
+    const int64_t adv = step > 0 ? hstep : 0;
+
+    // h_{t-1} W_hh^T, k-chunk by k-chunk, all eight blocks per chunk; one memory instruction per MFMA group in the first
+    // groups: the stores of h_{t-1}, the input rows of step + 2 to LDS, the requests for the rows of step + 3
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      float4 a_next = a;
+      if (m + 1 < 8) a_next = *reinterpret_cast<const float4*>(arow + 16 * (m + 1));
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[b] = mfma16(av[tt], wf[b][4 * m + tt], acc[b]);
+        const int slot = 4 * m + tt;
+        if (slot < 2) {
+          asm volatile("" : "+v"(hs[slot].x), "+v"(hs[slot].y), "+v"(hs[slot].z), "+v"(hs[slot].w));
+          if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
+          *reinterpret_cast<float4*>(hp[slot]) = hs[slot];
+          hp[slot] += adv;
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (slot < 4) {
+          dma_x(step + 2, step & 1, slot - 2);    // x_{step+2} -> the buffer of x_step (last read before the previous barrier)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      a = a_next;
+    }
+    // cell update of both unit halves (lane-local), h_t -> the other LDS buffer
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const LstmCell2 u = lstm_cell2((f32x2){acc[hf][r], acc[hf][r + 1]}, (f32x2){acc[2 + hf][r], acc[2 + hf][r + 1]},
+                                       (f32x2){acc[4 + hf][r], acc[4 + hf][r + 1]}, (f32x2){acc[6 + hf][r], acc[6 + hf][r + 1]},
+                                       (f32x2){cst[hf][r], cst[hf][r + 1]});
+        cst[hf][r] = u.c.x;
+        cst[hf][r + 1] = u.c.y;
+        hnext[(4 * ks + r) * L16_LDH + 32 * w + 16 * hf + i16] = u.h.x;
+        hnext[(4 * ks + r + 1) * L16_LDH + 32 * w + 16 * hf + i16] = u.h.y;
+      }
+    }
+    if (step + 1 < g.len) input_part((step + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's rows of x_{step+2} have landed (read behind the NEXT barrier)
+    __syncthreads();
+  }
+  {
+    const float* hfin = Hs + (g.len & 1) * 16 * L16_LDH;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 v = *reinterpret_cast<const float4*>(hfin + (srow + 2 * j) * L16_LDH + scol);
+      if (RELU) v = make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w));
+      *reinterpret_cast<float4*>(hp[j]) = v;
+    }
+  }
+}
+
 }  // namespace
 
 int lstm16x_launch(int nin, bool relu, int nst16, int ndir, void* stream, const float* x, int ldx, const float* const* wih,
                    const float* const* bih, const float* const* bhh, const float* const* whh, float* hc, int ldh,
                    int64_t dump_row, const SeqGeom& g) {
-  if (nin != 64 || nst16 < 1 || ndir < 1 || ndir > 2 || g.len < 1) return (int)hipErrorInvalidValue;
-  auto kern = relu ? lstm16x_kernel<64, true> : lstm16x_kernel<64, false>;
-  constexpr size_t lds = X16<64>::LDS_BYTES;
-  static PerDeviceOnce ready[2];
+  if ((nin != 64 && nin != 128) || nst16 < 1 || ndir < 1 || ndir > 2 || g.len < 1) return (int)hipErrorInvalidValue;
+  auto kern = nin == 64 ? (relu ? lstm16x_kernel<64, true> : lstm16x_kernel<64, false>)
+                        : (relu ? lstm16x128_kernel<true> : lstm16x128_kernel<false>);
+  const size_t lds = nin == 64 ? X16<64>::LDS_BYTES : X128_LDS_BYTES;
+  static PerDeviceOnce ready[4];
   const int dev = current_hip_device();
-  if (!ready[relu].done(dev)) {
+  const int ki = (nin == 128 ? 2 : 0) + (relu ? 1 : 0);
+  if (!ready[ki].done(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    ready[relu].set(dev);
+    ready[ki].set(dev);
   }
   const int r = ndir == 2 ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(nst16, ndir), dim3(256), lds, static_cast<hipStream_t>(stream), x, ldx, wih[0], wih[r], bih[0],
