@@ -615,6 +615,8 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the opt-in split-precision experiment leg")
     ap.add_argument("--pmc-run", action="store_true", help="warm-up + timed steps only (no per-kernel event pass, no isolated "
                     "pass, no CPU leg): the command rocprofv3 --pmc / --kernel-trace passes are taken over")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="engine option(s) for the headline engine "
+                    "(dptnav_set_option; experiments / A-B runs): the line then carries them under config.options")
     ap.add_argument("--serialize", action="store_true", help="with --pmc-run: option serialize = 1 (the step's sub-batch launches one "
                     "after the other on one stream), the pass bench.py's roofline figures are taken from")
     args = ap.parse_args()
@@ -631,7 +633,7 @@ def main():
     torch.cuda.set_device(dev)
     cfg, B_default, T, workload = CONFIGS[args.config]
     B, Tv = args.batch or B_default, 50
-    headline = args.config == "dptn_av" and not args.pmc_run and env.world == 1 and not args.batch
+    headline = args.config == "dptn_av" and not args.pmc_run and env.world == 1 and not args.batch and not args.opt
     if args.config != "dptn_av" or args.pmc_run:
         args.no_cpu_baseline = True     # the CPU leg is only defined for the headline configuration
     ddp_leg = args.config == "dptn_av" and not args.pmc_run and env.world > 1    # N > 1: data-parallel training leg on all ranks
@@ -650,6 +652,8 @@ def main():
     e1 = torch.from_numpy(inp["s1_embedding"]).to(dev) if not cfg.audio_only else None
     e2 = torch.from_numpy(inp["s2_embedding"]).to(dev) if not cfg.audio_only else None
     out = (torch.empty_like(mix), torch.empty_like(mix))
+    for kv in args.opt:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.serialize:
         if not args.pmc_run:
             raise SystemExit("--serialize is a profiling aid: use it with --pmc-run")
@@ -720,7 +724,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}, batch={B} per GPU, T={T}, random-init weights (numpy seed 0)",
-                       "batch_per_gpu": B, "samples": T, "tokens_per_mixture": S * K,
+                       "batch_per_gpu": B, "samples": T, "tokens_per_mixture": S * K, "options": args.opt or None,
                        "parallelism": f"dp{env.world} (batch shards, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": dom["kernel"], "class": dom["class"], "achieved": dom["achieved"],
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],

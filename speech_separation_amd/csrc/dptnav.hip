@@ -82,7 +82,7 @@ struct dptnav_ctx {
   bool opt_overlap = true;
   bool opt_serialize = false;       // measurement: dptnav_forward keeps its sub-batch cut but enqueues every launch on the caller's stream
   bool opt_lstm16 = true;
-  bool opt_fuse_pre128 = false;     // the same for num_features = 128 (lstm16x128_kernel: W_ih split between LDS and VGPRs)
+  bool opt_fuse_pre128 = true;      // the same for num_features = 128 (lstm16x128_kernel: W_ih split between LDS and VGPRs)
   bool opt_fuse_pre = true;         // num_features = 64, inference: the input projection runs INSIDE the recurrence (lstm16x.hip), no K4 launch, no PRE tensor
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)

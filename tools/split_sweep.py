@@ -20,6 +20,8 @@ for name, cfg in (("dptn_av", DPTN_AV), ("dptn_audio", DPTN_AUDIO)):
     eng = DptnEngine(cfg, dev)
     eng.bind(params_to_device(synthetic_state_dict(cfg, 0), dev))
     eng.set_option("lstm4", LSTM4)
+    for kv in filter(None, os.environ.get("SWEEP_OPTS", "").split(",")):      # e.g. SWEEP_OPTS=fuse_pre128=1,fuse_pre=0
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for B in BATCHES:
         inp = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=B, T=32000, Tv=50, seed=0).items()}
         args = (inp["mix"], inp.get("s1_embedding"), inp.get("s2_embedding"))
