@@ -266,10 +266,13 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 the pre-activations to the workspace (2 KiB per token and direction, read again by the recurrence); launches
  *                 small enough for the low-latency recurrence (lstm4) keep the GEMM.  Same sums in another order: results
  *                 agree with 0 to fp32 rounding (> 110 dB).
- *   "fuse_pre128" (0/1, default 1): the same for num_features = 128 (lstm16x128_kernel: W_ih is as large as W_hh, so 33 of a
- *                 wave's 64 W_ih fragment sets live in VGPRs and 31 in LDS; twice the matrix work per step).  Measured at
- *                 B = 16 x 4 s: the same step time as the GEMM + recurrence pair (29.75 vs 29.75 ms), 1.7-2 % faster from
- *                 B = 24, and 41.7 GB per step less HBM traffic (the pre-activation tensor was 80 % of a forward's).
+ *   "fuse_pre128" (0/1/2, default 1): the same for num_features = 128 (lstm16x128_kernel: W_ih is as large as W_hh, so 33 of a
+ *                 wave's 64 W_ih fragment sets live in VGPRs and 31 in LDS; twice the matrix work per step).  1 = for
+ *                 batches of at least 12 mixtures (a fused launch takes its 1.17 ms whatever its size: below that the chip
+ *                 is not full and the GEMM + recurrence pair is the shorter chain -- B = 8: 17.0 vs 18.0 ms); 2 = always;
+ *                 0 = never.  Measured at B = 16 x 4 s: the same step time as the pair (29.75 vs 29.75 ms), 1.7-2 %
+ *                 faster from B = 24, and 32.8 GB per step less HBM traffic (52.1 -> 19.3 GB: the pre-activation tensor was
+ *                 80 % of a forward's).
  *   "pack_whh" (0/1, default 1): the low-latency recurrence (lstm4) reads W_hh from a fragment-order copy made at its
  *                 first launch of a pass; bit-identical to 0.
  *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a

@@ -53,6 +53,7 @@ struct Run {
   int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
   bool packed_whh4 = false;          // ws + pl.whh4 holds the fragment-order W_hh copies of ALL paths for lstm4.hip (made at its first launch of the pass)
   bool packed_wih = false;           // ws + pl.wih holds the fragment-order W_ih copies of ALL paths; otherwise run_path packs its own
+  bool fuse128 = false;              // num_features = 128: input projection inside the recurrence for this pass (dptnav_ctx::fuse128_for)
   bool packed = false;               // ws + pl.wpack holds the packed weights of ALL paths (dptnav_forward); otherwise
                                      // run_path packs the path it is about to run
   unsigned* take_queue(int n) {
@@ -82,7 +83,10 @@ struct dptnav_ctx {
   bool opt_overlap = true;
   bool opt_serialize = false;       // measurement: dptnav_forward keeps its sub-batch cut but enqueues every launch on the caller's stream
   bool opt_lstm16 = true;
-  bool opt_fuse_pre128 = true;      // the same for num_features = 128 (lstm16x128_kernel: W_ih split between LDS and VGPRs)
+  int opt_fuse_pre128 = 1;          // the same for num_features = 128 (lstm16x128_kernel: W_ih split between LDS and VGPRs): 0 never, 2 always,
+                                    // 1 (default) from B = 12: a fused launch is 1.17 ms whatever its size -- below that the chip is not full
+                                    // and the shorter K4 + recurrence chain wins (B = 8: 17.0 vs 18.0 ms; B = 16: equal; B = 24: 44.8 vs 44.0)
+  bool fuse128_for(int B) const { return opt_fuse_pre128 == 2 || (opt_fuse_pre128 == 1 && B >= 12); }
   bool opt_fuse_pre = true;         // num_features = 64, inference: the input projection runs INSIDE the recurrence (lstm16x.hip), no K4 launch, no PRE tensor
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
@@ -652,7 +656,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
                     (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= 23 * c->num_cus));
   // num_features = 64: input projection inside the recurrence (lstm16x.hip) -- no K4 launch, no pre-activation tensor
-  const bool usex = (N == 64 ? c->opt_fuse_pre : c->opt_fuse_pre128) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
+  const bool usex = (N == 64 ? c->opt_fuse_pre : run.fuse128) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   if (!usex) {
     ALoadSeqTile al{lstm_in, N, geom};
@@ -1941,6 +1945,7 @@ int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, f
   if (int rc = check_common(h, B, T, 1, ws, ws_bytes, &pl)) return rc;
   Run run;
   if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
+  run.fuse128 = h->fuse128_for(B);
   return h->cfg.num_features == 128 ? run_path<128>(h, run, block, path, x_in, x_out, B, S)
                                     : run_path<64>(h, run, block, path, x_in, x_out, B, S);
 }
@@ -2008,6 +2013,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
   for (int i = 0; i < nsub; ++i) {
     hipStream_t si = forked ? h->streams[i % nstr] : st;   // sub-batches go round robin over the internal streams
     if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
+    run[i].fuse128 = h->fuse128_for(B);      // by the forward's whole batch, not the sub-batch
     mixi[i] = mix + b0 * T;
     e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
     e2i[i] = e2 ? e2 + b0 * Cv * Tv : nullptr;
@@ -2524,7 +2530,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
   else if (k == "fuse_pre") h->opt_fuse_pre = value != 0;
-  else if (k == "fuse_pre128") h->opt_fuse_pre128 = value != 0;
+  else if (k == "fuse_pre128" && value >= 0 && value <= 2) h->opt_fuse_pre128 = value;
   else if (k == "pack_whh") h->opt_pack_whh = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;
   else if (k == "lstm4") {

@@ -58,6 +58,8 @@ def resample(wave: torch.Tensor, orig_sr: int, new_sr: int, lowpass_filter_width
     ``torchaudio.functional.resample(audio, sr, target_sr)`` (base_dataset.py:142-148) computes with its defaults --
     windowed-sinc interpolation (Hann window, 6 zero crossings, cut-off at 0.99 of the lower Nyquist) applied as one strided
     convolution with `new_sr / gcd` polyphase kernels; output length ceil(T * new_sr / orig_sr).
+    The kernels are formed in the WAVEFORM's dtype, as torchaudio does (it passes `waveform.dtype` to its kernel builder: for
+    the float32 audio the reference loads, idx, t, window and kernel are all float32) -- ADVICE r3.
     torchaudio is a third-party dependency that is not installed here and the reference holds no fixture for it: PARITY
     UNPINNED (properties only: tests/test_io.py)."""
     import math
@@ -69,15 +71,16 @@ def resample(wave: torch.Tensor, orig_sr: int, new_sr: int, lowpass_filter_width
     orig, new = int(orig_sr) // g, int(new_sr) // g
     base = min(orig, new) * rolloff
     width = int(math.ceil(lowpass_filter_width * orig / base))
-    idx = torch.arange(-width, width + orig, dtype=torch.float64) / orig
-    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx[None, :]
+    kdt = wave.dtype if wave.dtype in (torch.float32, torch.float64) else torch.float32
+    idx = torch.arange(-width, width + orig, dtype=kdt) / orig
+    t = torch.arange(0, -new, -1, dtype=kdt)[:, None] / new + idx[None, :]
     t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
     window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
     t = t * math.pi
     kernels = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)      # (new, 2 width + orig)
     shape, T = wave.shape[:-1], wave.shape[-1]
-    x = torch.nn.functional.pad(wave.reshape(-1, 1, T).to(torch.float32), (width, width + orig))
-    y = torch.nn.functional.conv1d(x, kernels.to(torch.float32)[:, None, :], stride=orig)           # (n, new, frames)
+    x = torch.nn.functional.pad(wave.reshape(-1, 1, T).to(kdt), (width, width + orig))
+    y = torch.nn.functional.conv1d(x, kernels[:, None, :], stride=orig)                             # (n, new, frames)
     y = y.transpose(1, 2).reshape(y.shape[0], -1)[:, :int(math.ceil(new * T / orig))]
     return y.reshape(*shape, y.shape[-1])
 

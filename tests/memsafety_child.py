@@ -41,7 +41,7 @@ VARIANTS = {
     "dptn128": (_cfg(DPTN_AV, num_blocks=2), {}, 5, 8000, 13, 3),
     "dptn128_lstm32": (_cfg(DPTN_AV, num_blocks=2), {"lstm16": 0, "lstm4": 0}, 5, 8000, 13, 3),
     "dptn128_lstm4": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 2}, 5, 8000, 13, 3),
-    "dptn128_lstm16x": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 0}, 5, 8000, 13, 0),                     # input projection inside the recurrence
+    "dptn128_lstm16x": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 0, "fuse_pre128": 2}, 5, 8000, 13, 0),   # input projection inside the recurrence
     "dptn128_pre": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 0, "fuse_pre128": 0}, 5, 8000, 13, 0),      # ... and the K4 + lstm16 path
     "dptn128_unfused": (_cfg(DPTN_AV, num_blocks=2), {"fuse_attn": 0, "fold_tail": 0, "pack_wih": 0, "pack_whh": 0}, 4, 6000, 7, 2),
     "dptn128_long": (_cfg(DPTN_AV, num_blocks=1), {}, 2, 48000, 50, 1),          # inter-chunk sequences > 160: streaming attention
