@@ -102,6 +102,8 @@ struct dptnav_ctx {
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
   bool opt_debug_sync = false;      // debugging aid: name every launch class on stderr and synchronise behind it
+  bool opt_train_fuse_probe = false;   // MEASUREMENT ONLY (tools/train_fuse_probe.py): the training forward runs the inference attention block
+                                       // (no qkv / att / LayerNorm tape: a backward after it is garbage) -- the upper bound of a fused front half
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
   DropCfg drop_cfg(int block, int path, bool train, int half = 0) const {
@@ -582,7 +584,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
 
   // K1 + K2 + K3 in one launch (inference, N = 128, sequences of <= 160 positions): QKV and the attention output never
   // leave the chip -- 1 kB of HBM traffic per token instead of 5.5 kB
-  const bool fused = dptn && !pb.train && path_fusable<N>(c, path, B, S);
+  const bool fused = dptn && (!pb.train || c->opt_train_fuse_probe) && path_fusable<N>(c, path, B, S);
   if (fused && (chain & CHAIN_PRO) && c->pw[2 * block + path - 1].ndir != 2)
     return c->fail(DPTNAV_ERR_INVALID, "internal: FFN prologue needs both LSTM directions of the previous path");
   if (fused && N == 64) {
@@ -2553,6 +2555,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "lstm_diag") h->opt_lstm_diag = (int)value;
   else if (k == "inject_fail") h->opt_inject_fail = value;
   else if (k == "debug_sync") h->opt_debug_sync = value != 0;
+  else if (k == "train_fuse_probe") h->opt_train_fuse_probe = value != 0;
   else return h->fail(DPTNAV_ERR_INVALID, "unknown option '%s'", key);
   return DPTNAV_OK;
 }
