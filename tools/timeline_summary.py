@@ -24,14 +24,16 @@ else:                    # a forward ends with the decoder gathers of its sub-ba
 sel = [e for e in ev if e[0] >= s0 and e[1] <= s1 + 1e6]
 pts = sorted([(a, 1, n) for a, b, n in sel] + [(b, -1, n) for a, b, n in sel])
 act, cur, lastt = collections.Counter(), 0, s0
-hist, alone = collections.Counter(), collections.Counter()
+hist, alone, rhist = collections.Counter(), collections.Counter(), collections.Counter()
+REC = ("lstm16", "bptt", "lstm_recurrence", "lstm4_kernel")      # (lstm16 also matches lstm16x / lstm16x128: the fused recurrences)
 lstm_active = lstm_alone = 0
 for t, d, n in pts:
     dt = t - lastt
     if dt > 0:
         hist[cur] += dt
         live = [k for k in act if act[k] > 0]
-        is_lstm = any(("lstm16" in k or "bptt" in k or "lstm_recurrence" in k) for k in live)
+        is_lstm = any(any(r in k for r in REC) for k in live)
+        rhist[sum(act[k] for k in live if any(r in k for r in REC))] += dt
         if cur == 1:
             alone[live[0][:70]] += dt
         if is_lstm:
@@ -44,6 +46,7 @@ for t, d, n in pts:
 print(f"last step: {(s1 - s0) / 1e6:.2f} ms, {len(sel)} launches")
 print("kernels in flight -> ms:", {k: round(v / 1e6, 2) for k, v in sorted(hist.items())})
 print(f"a recurrence in flight {lstm_active / 1e6:.2f} ms, of which as the ONLY kernel {lstm_alone / 1e6:.2f} ms")
+print("recurrence launches in flight -> ms:", {k: round(v / 1e6, 2) for k, v in sorted(rhist.items())})
 print("alone on the chip (ms):")
 for k, v in alone.most_common(8):
     print(f"  {v / 1e6:7.2f}  {k}")
