@@ -125,3 +125,25 @@ def test_dropout_generator_statistics():
     assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 2e-3
     h = np.histogram(u, bins=64)[0] / (u.size / 64)
     assert h.min() > 0.97 and h.max() < 1.03
+
+
+def _build_c_consumer(tmp_path):
+    """gcc -std=c99 -pedantic on tests/cabi/consumer.c against include/dptnav.h + libdptnav.so: the header is plain C and the
+    library links from C (no C++ runtime symbols, no HIP headers, no torch on the consumer's side)."""
+    import subprocess
+    from speech_separation_amd.build import OUT, build_lib
+    build_lib()
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.dirname(OUT)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "consumer.c"),
+           "-o", exe, "-L", libdir, "-l:libdptnav.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_c_consumer_compiles_links_and_gets_clean_errors(tmp_path):
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok host" in r.stdout, r.stdout + r.stderr
