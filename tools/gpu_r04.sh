@@ -9,15 +9,6 @@ export TMPDIR=/tmp
 COMMIT="$(cat $R/.commit 2>/dev/null || echo unknown)"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 cd $R
-if has bench; then
-  timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { echo bench failed; tail -20 $O/${TAG}_bench.err; exit 1; }
-  python - <<PY
-import json
-d=json.load(open("$O/${TAG}_bench.json"))
-print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"]["class"], d["roofline"]["frac"], d["roofline"]["launch_ms"], "train", d.get("train_step",{}).get("value"),
-      "b1", d.get("latency_b1",{}).get("mean_ms"), "others", {k: v.get("value") for k, v in d.get("other_configs",{}).items()})
-PY
-fi
 cd /tmp
 if has trace; then
   for MODE in "" "--serialize"; do
@@ -71,5 +62,21 @@ if has train; then
   (cd $R && python3 tools/pmc_table.py --forwards 2 --config dptn_av_train --command "python3 bench.py --config dptn_av_train --pmc-run --steps 1 --warmup 1" --commit "$COMMIT" \
       --out $O/${TAG}_train_pmc_traffic.json $O/${TAG}_tp_FETCH_SIZE $O/${TAG}_tp_WRITE_SIZE | head -6)
   rm -rf $O/${TAG}_tp_FETCH_SIZE $O/${TAG}_tp_WRITE_SIZE
+fi
+if has bench; then
+  # the bench line quotes the traffic tables: give it the ones just taken (same tree, same digest)
+  for f in pmc_traffic.json pmc_traffic_dptn_audio.json pmc_traffic_dprnn_av.json train_pmc_traffic.json; do
+    [ -f $O/${TAG}_$f ] && cp $O/${TAG}_$f $R/profiles/r04_$f
+  done
+fi
+cd $R
+if has bench; then
+  timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { echo bench failed; tail -20 $O/${TAG}_bench.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("$O/${TAG}_bench.json"))
+print("value", d["value"], "ms", d["ms_per_step"], "roofline", d["roofline"]["class"], d["roofline"]["frac"], d["roofline"]["launch_ms"], "train", d.get("train_step",{}).get("value"),
+      "b1", d.get("latency_b1",{}).get("mean_ms"), "others", {k: v.get("value") for k, v in d.get("other_configs",{}).items()})
+PY
 fi
 ls -la $O | grep ${TAG}_ | tail -20
