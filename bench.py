@@ -258,7 +258,7 @@ def train_step_leg(cfg, dev, T, B=16, warmup=4, steps=12, env=None):
     res = {"workload": f"configs[3]: DPTN-AV training step (PIT SI-SNR loss + AdamW, clip 10), batch={B} per GPU, T={T}, dropout 0.1",
            "value": round(world * B / dt, 3), "unit": "mixtures/sec", "n_gpus": world, "ms_per_step": round(1e3 * dt, 3), "steps": steps,
            "warmup": warmup, "frac": round(flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-           "parallelism": f"dp{world}" + (" (one flat 17.8 MB gradient all-reduce per step over RCCL, then clip + AdamW on every rank)" if world > 1 else ""),
+           "parallelism": f"dp{world}" + (f" (one flat 17.8 MB gradient all-reduce per step over {'RCCL' if env.backend == 'nccl' else env.backend}, then clip + AdamW on every rank)" if world > 1 else ""),
            "note": "frac = 3 x forward FLOPs (612 GFLOP per mixture) / time / fp32-MFMA peak, per GPU; no host synchronisation in the step",
            "last_loss": round(float(stats["loss"]), 4)}
     if world > 1:
