@@ -56,24 +56,41 @@ DEV void group_sum32_x4(float (&v)[4]) {
     v[i] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
   }
 }
-// LayerNorm of four rows at once: v[i] = this lane's 4 columns of row i (a row = 32 adjacent lanes)
+// LayerNorm of four rows at once: v[i] = this lane's 4 columns of row i (a row = 32 adjacent lanes).  The element-wise part is
+// written on 2-vectors so that it issues as packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two columns per issue;
+// beside fp32 MFMAs every vector instruction costs its issue time, section 3.5 of DESIGN.md)
 DEV void layernorm_rows_x4(float4 (&v)[4], const float4 ga, const float4 be) {
+  f32x2 lo[4], hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lo[i] = (f32x2){v[i].x, v[i].y};
+    hi[i] = (f32x2){v[i].z, v[i].w};
+  }
   float s[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 t = lo[i] + hi[i];
+    s[i] = t.x + t.y;
+  }
   group_sum32_x4(s);
   float q[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float mu = s[i] * (1.0f / N);
-    v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
-    q[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    const f32x2 m2 = (f32x2){mu, mu};
+    lo[i] -= m2;
+    hi[i] -= m2;
+    const f32x2 t = lo[i] * lo[i] + hi[i] * hi[i];
+    q[i] = t.x + t.y;
   }
   group_sum32_x4(q);
+  const f32x2 galo = (f32x2){ga.x, ga.y}, gahi = (f32x2){ga.z, ga.w}, belo = (f32x2){be.x, be.y}, behi = (f32x2){be.z, be.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float rstd = rsqrtf(q[i] * (1.0f / N) + 1e-5f);
-    v[i] = make_float4(v[i].x * rstd * ga.x + be.x, v[i].y * rstd * ga.y + be.y, v[i].z * rstd * ga.z + be.z, v[i].w * rstd * ga.w + be.w);
+    const f32x2 r2 = (f32x2){rstd, rstd};
+    const f32x2 a = lo[i] * r2 * galo + belo, b = hi[i] * r2 * gahi + behi;
+    v[i] = make_float4(a.x, a.y, b.x, b.y);
   }
 }
 // MFMAs issued by iteration kb of the softmax pipeline: PV(kb-1) (kb > 0) + S(kb+1) (kb + 1 < nkb), 16 each
@@ -153,6 +170,17 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   const int seq = blockIdx.x, len = g.len;
   const int64_t tok0 = seq_token_base(g, seq);
   const int tstride = seq_token_stride(g);
+  // Row addresses as a wave-uniform 64-bit base (the sequence's first token) + a 32-bit byte offset per lane
+  // (row x stride: < 160 x 150 x 1 KiB): the loads / stores then take the base from SGPRs and the offset costs a v_min (last
+  // block only), a 24-bit multiply and an add -- written with 64-bit token arithmetic per access it was ~600 of the kernel's
+  // 3 100 vector instructions (v_mul_lo_u32 at a quarter of the rate among them), beside fp32 MFMAs that pay for each one.
+  const unsigned rs_h = (unsigned)tstride * 1024u;       // bytes between consecutive positions in hc [M][256]
+  const unsigned rs_y = (unsigned)tstride * 512u;        // ... in x / y1 [M][128]
+  char* const ybase = reinterpret_cast<char*>(y1) + tok0 * 512;
+  auto row_off = [&](int row, unsigned rstride, bool clamp) -> unsigned {      // row = uniform part + lane part, < 2^24
+    if (clamp) row = row < len ? row : len - 1;
+    return (unsigned)__umul24((unsigned)row, rstride);
+  };
 
   AB_DECL
   // This head's W_k / W_v fragments, resident through phase 1.  The row-per-lane fragment loads (32 rows x 32 bytes per
@@ -215,7 +243,8 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       if constexpr (rb + 2 < NKB) fetch_h(rb + 2, hst[rb & 1]);
       float4 res[4];                         // residual rows y1_prev of this thread's four row-space slots
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) res[pass] = ldg4(y1 + tok_of(rb * 32 + pass * 8 + prs) * N + 4 * pc4);
+      for (int pass = 0; pass < 4; ++pass)
+        res[pass] = *reinterpret_cast<const float4*>(ybase + row_off(rb * 32 + pass * 8 + prs, rs_y, rb == NKB - 1) + 16u * pc4);
       f32x16 a0 = zero16(), a1 = zero16();
       const float* ar = &Hs[c * LDHC + 4 * hh];
 #pragma unroll
@@ -234,7 +263,11 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       AB_KEEP(a0[15]) AB_KEEP(a1[15])
       AB_MARK(2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Cs[ROW32(r, hh) * LDP + 32 * h + c] = a0[r] + a1[r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = (f32x2){a0[r], a0[r + 1]} + (f32x2){a1[r], a1[r + 1]};
+        Cs[ROW32(r, hh) * LDP + 32 * h + c] = t.x;
+        Cs[ROW32(r + 1, hh) * LDP + 32 * h + c] = t.y;
+      }
       __syncthreads();
       AB_MARK(3)
       {
@@ -242,8 +275,9 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
           const float4 cv = *reinterpret_cast<const float4*>(&Cs[(pass * 8 + prs) * LDP + 4 * pc4]);
-          v[pass].x = cv.x + bfc.x + res[pass].x; v[pass].y = cv.y + bfc.y + res[pass].y;
-          v[pass].z = cv.z + bfc.z + res[pass].z; v[pass].w = cv.w + bfc.w + res[pass].w;
+          const f32x2 lo = (f32x2){cv.x, cv.y} + (f32x2){bfc.x, bfc.y} + (f32x2){res[pass].x, res[pass].y};
+          const f32x2 hi = (f32x2){cv.z, cv.w} + (f32x2){bfc.z, bfc.w} + (f32x2){res[pass].z, res[pass].w};
+          v[pass] = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
         layernorm_rows_x4(v, g2c, b2c);
 #pragma unroll
@@ -259,7 +293,8 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int row = i * 8 + (tid >> 5);
-      st[i] = ldg4(x + (tok0 + (int64_t)(row < len ? row : len - 1) * tstride) * N + 4 * (tid & 31));
+      st[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + tok0 * 512 + row_off(row, rs_y, i >= 4 * (NKB - 1)) +
+                                               16u * (tid & 31));
     }
     fetch_wkv();
 #pragma unroll
@@ -308,9 +343,13 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
         }
       }
 #pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 tk = (f32x2){ka[r], ka[r + 1]} + (f32x2){bk[r], bk[r + 1]}, tv = (f32x2){va[r], va[r + 1]} + (f32x2){bv, bv};
+        kt[rb][r] = tk.x; kt[rb][r + 1] = tk.y;
+        vv[rb][r] = tv.x; vv[rb][r + 1] = tv.y;
+      }
+#pragma unroll
       for (int r = 0; r < 16; ++r) {
-        kt[rb][r] = ka[r] + bk[r];
-        vv[rb][r] = va[r] + bv;
         // parked in the AGPR half of the register file (one wave per SIMD: 256 + 256 registers per lane); the MFMAs of
         // phase 2 read their A operand there
         asm volatile("" : "+a"(kt[rb][r]), "+a"(vv[rb][r]));
@@ -375,10 +414,11 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       const float4 a2 = *reinterpret_cast<const float4*>(pr + 64 * LDP);
       const float4 a3 = *reinterpret_cast<const float4*>(pr + 96 * LDP);
       const float4 xres = *reinterpret_cast<const float4*>(&Xs[(qb * 32 + row) * LDX + 4 * c4]);
-      v[pass].x = ((a0.x + a1.x) + (a2.x + a3.x)) + bo.x + xres.x;
-      v[pass].y = ((a0.y + a1.y) + (a2.y + a3.y)) + bo.y + xres.y;
-      v[pass].z = ((a0.z + a1.z) + (a2.z + a3.z)) + bo.z + xres.z;
-      v[pass].w = ((a0.w + a1.w) + (a2.w + a3.w)) + bo.w + xres.w;
+      const f32x2 lo = (((f32x2){a0.x, a0.y} + (f32x2){a1.x, a1.y}) + ((f32x2){a2.x, a2.y} + (f32x2){a3.x, a3.y})) + (f32x2){bo.x, bo.y} +
+                       (f32x2){xres.x, xres.y};
+      const f32x2 hi = (((f32x2){a0.z, a0.w} + (f32x2){a1.z, a1.w}) + ((f32x2){a2.z, a2.w} + (f32x2){a3.z, a3.w})) + (f32x2){bo.z, bo.w} +
+                       (f32x2){xres.z, xres.w};
+      v[pass] = make_float4(lo.x, lo.y, hi.x, hi.y);
     }
     layernorm_rows_x4(v, ga, be);
     // Straight-line on purpose (a branch per row would cut this region into basic blocks and nothing could be scheduled
@@ -387,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int p = qb * 32 + pass * 8 + rsub;
-      *reinterpret_cast<float4*>(y1 + (tok0 + (int64_t)(p < len ? p : len - 1) * tstride) * N + 4 * c4) = v[pass];
+      *reinterpret_cast<float4*>(ybase + row_off(p, rs_y, true) + 16u * c4) = v[pass];
     }
   };
   f32x16 qa = zero16(), qb_ = zero16();
@@ -397,7 +437,11 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
   for (int qb = 0; qb < NKB; ++qb) {
     f32x16 q;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) q[r] = (qa[r] + qb_[r] + qbias[r]) * scale_log2e;
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 t = ((f32x2){qa[r], qa[r + 1]} + (f32x2){qb_[r], qb_[r + 1]} + (f32x2){qbias[r], qbias[r + 1]}) * (f32x2){scale_log2e, scale_log2e};
+      q[r] = t.x;
+      q[r + 1] = t.y;
+    }
     __builtin_amdgcn_sched_barrier(0);
     // Streaming softmax over the key blocks; O^T accumulated transposed (lane = query).  One wave per SIMD, so nothing
     // runs beside this wave: the loop is a two-stage pipeline in which iteration kb issues the MFMAs of
@@ -447,13 +491,17 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
       const float mnew = (kb == 0 || mx > mrun + 8.0f) ? mx : mrun;
       const float alpha = fast_exp2(mrun - mnew);
       f32x16 p;
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x2 s2[2] = {(f32x2){0.f, 0.f}, (f32x2){0.f, 0.f}};      // four partial sums, two per packed add
+      const f32x2 mn2 = (f32x2){mnew, mnew};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[r] = fast_exp2(s[r] - mnew);
-        s4[r & 3] += p[r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 dlt = (f32x2){s[r], s[r + 1]} - mn2;
+        const f32x2 e = (f32x2){fast_exp2(dlt.x), fast_exp2(dlt.y)};
+        p[r] = e.x;
+        p[r + 1] = e.y;
+        s2[(r >> 1) & 1] += e;
       }
-      const float sum = half_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+      const float sum = half_sum((s2[0].x + s2[0].y) + (s2[1].x + s2[1].y));
       lrun = lrun * alpha + sum;
       // one MFMA, then a few vector instructions, ... (the groups are taken from this region in program order)
       constexpr int NM = kb_mfmas(kb, NKB);
@@ -490,7 +538,11 @@ __global__ __launch_bounds__(256) void attn_block_kernel(const float* __restrict
     {
       const float inv = fast_rcp(lrun);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= inv;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = (f32x2){o[r], o[r + 1]} * (f32x2){inv, inv};
+        o[r] = t.x;
+        o[r + 1] = t.y;
+      }
     }
     AB_KEEP(o[15])
     AB_MARK(8)
@@ -768,7 +820,11 @@ __global__ __launch_bounds__(256) void attn_block_split_kernel(const float* __re
     {
       const float inv = fast_rcp(lrun);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= inv;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = (f32x2){o[r], o[r + 1]} * (f32x2){inv, inv};
+        o[r] = t.x;
+        o[r + 1] = t.y;
+      }
     }
     bf16x8 oh[2], ol[2];
     split_tile(o, oh, ol);
