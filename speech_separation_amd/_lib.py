@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdptnav.so")
+# DPTNAV_LIB: another build of the library (same-box A/B of two builds: tools/train_ab.py, tools/ab_option.py)
+LIB_PATH = os.environ.get("DPTNAV_LIB") or os.path.join(_HERE, "libdptnav.so")
 ABI_VERSION = 3
 
 
