@@ -52,6 +52,8 @@ VARIANTS = {
     "dprnn": (_cfg(DPRNN_AV, num_blocks=2), {}, 3, 4000, 9, 2),
     "dprnn_lstm32": (_cfg(DPRNN_AV, num_blocks=2), {"lstm16": 0, "lstm4": 0}, 3, 4000, 9, 2),
     "dprnn_lstm16x": (_cfg(DPRNN_AV, num_blocks=2), {"lstm4": 0}, 3, 4000, 9, 0),
+    "dprnn_fcln3": (_cfg(DPRNN_AV, num_blocks=2), {"fcln64": 2}, 3, 4000, 9, 0),              # fcln64.hip, two tiles ahead (default: one)
+    "dprnn_fc_engine": (_cfg(DPRNN_AV, num_blocks=2), {"fcln64": 0}, 3, 4000, 9, 0),          # ... and the GEMM engine's fc + LayerNorm
     "unidir128": (_cfg(DPTN_AV, num_blocks=2, bidir=False), {}, 5, 8000, 13, 3),
     "unidir64": (_cfg(DPTN_AUDIO, num_blocks=2, bidir=False), {}, 4, 8000, 1, 2),
     "split_bf16": (_cfg(DPTN_AV, num_blocks=2), {"split_bf16": 1}, 5, 8000, 13, 0),
