@@ -77,6 +77,9 @@ class GuardArena:
         self.total += nbytes
         base, mapped = C.c_void_p(), C.c_size_t()
         self.lib.gm_mapped_range(h, C.byref(base), C.byref(mapped))
+        if os.environ.get("GUARDMEM_LOG"):      # one line per allocation: a fault address can be looked up afterwards
+            with open(os.environ["GUARDMEM_LOG"], "a") as fh:
+                fh.write(f"{len(self.handles)} flush={self.flush} bytes={nbytes} user=0x{p.value:x} mapped=[0x{base.value:x}, 0x{base.value + mapped.value:x})\n")
         whole = torch.as_tensor(_Raw(base.value, mapped.value, self), device=f"cuda:{self.dev}")
         whole.fill_(self.fill)
         t = torch.as_tensor(_Raw(p.value, nbytes, self), device=f"cuda:{self.dev}")
