@@ -285,6 +285,8 @@ def bench_train(args, env, cfg, B, T, workload):
     inp = synthetic_inputs(cfg, B=B, T=T, Tv=50, seed=123 + env.rank)
     batch0 = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
     crit = SiSNRWavLoss()
+    for kv in args.opt:                                # (experiments / A-B runs, tools/train_ab.py)
+        model._get_engine(dev).set_option(kv.split("=")[0], int(kv.split("=")[1]))
     log(f"rank {env.rank}/{env.world} on {dev}: training warm-up")
     stats = None
     for _ in range(args.warmup):
@@ -378,7 +380,7 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
     flops, ffn_rides = class_flops_per_step(cfg, prof, B, S, eng.frames(T))
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     ndir = 2 if cfg.bidir else 1
-    dprnn_fc = cfg.arch != "dptn" and cfg.num_features == 64 and cfg.bidir       # (option fcln64, default on: run_path in dptnav.hip)
+    dprnn_fc = cfg.arch != "dptn" and cfg.num_features == 64 and cfg.bidir       # (option fcln, default on: run_path in dptnav.hip)
     rows = []
     for cls, fl in flops.items():
         ms, n = prof.get(cls, (0.0, 0))
@@ -416,14 +418,14 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
                        ("attn_block_kernel" if fused else "attention_kernel"))
         else:
             row.update(kernel={"lstm_pre_gemm": "gemm_ws_kernel<..., EpiLstmPre*> (x W_ih^T + b, fragment-order store)",
-                               "ffn_ln_gemm": "fcln64_kernel (DPRNN: LayerNorm(h W_fc^T + b) + x on 16-token tiles)" if dprnn_fc else
+                               "ffn_ln_gemm": "fcln_kernel (DPRNN: LayerNorm(h W_fc^T + b) + x on 16-token tiles)" if dprnn_fc else
                                "gemm_ws_kernel<..., EpiBiasResLN> (ReLU(h) W_f^T + b + y1, LayerNorm 2)",
                                "qkv_gemm": "gemm_ws_kernel<..., EpiBiasStore> (in-projection)",
                                "outproj_ln_gemm": "gemm_ws_kernel<..., EpiBiasResLN> (out-projection + residual + LayerNorm 1)",
                                "sep_gemm": "gemm_ws_kernel<..., ALoadDensePReLU, EpiBiasStore> (PReLU + 1x1 conv N -> 2N)",
                                "postproc_gemm": "taps_fold_kernel (OLA gather + post-processing conv + skip + decoder taps)"}[cls],
                        pmc_match={"lstm_pre_gemm": "EpiLstmPre", "sep_gemm": "ALoadDensePReLU", "postproc_gemm": "taps_fold_kernel",
-                                  "ffn_ln_gemm": "fcln64_kernel" if dprnn_fc else "ALoadColsT<false>, EpiBiasResLN"}.get(cls))
+                                  "ffn_ln_gemm": "fcln_kernel" if dprnn_fc else "ALoadColsT<false>, EpiBiasResLN"}.get(cls))
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows

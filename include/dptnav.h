@@ -273,11 +273,13 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 0 = never.  Measured at B = 16 x 4 s: the same step time as the pair (29.75 vs 29.75 ms), 1.7-2 %
  *                 faster from B = 24, and 32.8 GB per step less HBM traffic (52.1 -> 19.3 GB: the pre-activation tensor was
  *                 80 % of a forward's).
- *   "fcln64" (0/1/2, default 1): DPRNN blocks with num_features = 64 and two directions, inference: Linear(256 -> 64) + LayerNorm +
- *                 residual (dprnn.py:41-45, 83-87) by fcln64.hip -- 16-token tiles fetched by LDS-DMA, three workgroups per CU
- *                 and one tile ahead (1) or two per CU and two tiles ahead (2) -- instead of the GEMM engine's 64-token
- *                 tiles, one workgroup per CU (0).  Same sums in another order (> 110 dB to 0).  B = 32 x 16 s: 1.25 / 1.21
- *                 vs 1.64 ms per launch alone on the chip, 327.1 / 327.8 vs 332.6 ms per forward.
+ *   "fcln" (0/1/2, default 1): a Linear layer with its LayerNorm and residual by fcln.hip -- 16-token tiles fetched by LDS-DMA,
+ *                 two or three workgroups per CU -- instead of the GEMM engine's 32- / 64-token tiles, one workgroup per CU (0):
+ *                 (a) DPRNN blocks with num_features = 64 and two directions, inference: Linear(256 -> 64) + LayerNorm +
+ *                 residual (dprnn.py:41-45, 83-87); 1 = one tile ahead, three workgroups per CU, 2 = two ahead, two per CU.
+ *                 B = 32 x 16 s: 1.25 / 1.21 vs 1.64 ms per launch alone on the chip, 327.1 / 327.8 vs 332.6 ms per forward;
+ *                 (b) the training forward with num_features = 128: out-projection + LayerNorm 1 and ReLU -> Linear +
+ *                 LayerNorm 2 (dptn.py:46-47, 50-51) with the LayerNorm tape.  Same sums in another order (> 100 dB to 0).
  *   "pack_whh" (0/1, default 1): the low-latency recurrence (lstm4) reads W_hh from a fragment-order copy made at its
  *                 first launch of a pass; bit-identical to 0.
  *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a

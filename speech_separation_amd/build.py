@@ -25,7 +25,7 @@ SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "
            "attn_block64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm16s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-           "lstm16x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "fcln64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+           "lstm16x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "fcln.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _headers():

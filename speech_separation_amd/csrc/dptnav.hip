@@ -18,7 +18,7 @@
 #include "headtail.h"
 #include "lstm.h"
 #include "lstm16.h"
-#include "fcln64.h"
+#include "fcln.h"
 #include "sisnr.h"
 #include "train_tail.h"
 #include "backward.h"
@@ -88,8 +88,9 @@ struct dptnav_ctx {
                                     // 1 (default) from B = 12: a fused launch is 1.17 ms whatever its size -- below that the chip is not full
                                     // and the shorter K4 + recurrence chain wins (B = 8: 17.0 vs 18.0 ms; B = 16: equal; B = 24: 44.8 vs 44.0)
   bool fuse128_for(int B) const { return opt_fuse_pre128 == 2 || (opt_fuse_pre128 == 1 && B >= 12); }
-  int opt_fcln64 = 1;               // DPRNN, num_features = 64, two directions, inference: Linear(256 -> 64) + LayerNorm + residual by fcln64.hip (1: three
-                                    // workgroups per CU, one tile ahead; 2: two per CU, two tiles ahead; 0: the GEMM engine)
+  int opt_fcln = 1;                 // Linear + LayerNorm + residual on 16-token tiles, several workgroups per CU (fcln.hip) instead of the GEMM engine (0):
+                                    // DPRNN fc (64 features, two directions, inference; 2 = two tiles ahead, two workgroups per CU) and the
+                                    // training forward's out-projection + LN1 / FFN + LN2 with the LayerNorm tape (128 features)
   bool opt_fuse_pre = true;         // num_features = 64, inference: the input projection runs INSIDE the recurrence (lstm16x.hip), no K4 launch, no PRE tensor
   bool opt_pack_whh = true;         // lstm4.hip reads W_hh from a fragment-order copy made at its first launch of a pass (0: row per lane)
   bool opt_pack_wih = true;         // K4 reads W_ih from a fragment-order copy made once per pass (0: from the nn.Module tensor, row per lane)
@@ -638,7 +639,13 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     ALoadDense al{att, M, N, BM};
     bool done = false;
     {
-      if (pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
+      if (pb.train && pb.zn1 && N == 128 && c->opt_fcln) {   // 16-token tiles, three workgroups per CU (fcln.hip)
+        FclnArgs fa{att, w.out_w, w.out_b, w.ln1_w, w.ln1_b, x_in, y1, pb.zn1, pb.rs1, M, N, N, true, false, 2};
+        ProfScope ps(c, CAT_OUTPROJ, st);
+        const int rc = fcln_launch(st, fa, c->num_cus);
+        if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (out-projection): %s", hipGetErrorString((hipError_t)rc));
+        done = true;
+      } else if (pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
         EpiBiasResLNSave<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM, pb.zn1, pb.rs1};
         if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm (tape)", w.out_w, ntiles, 1, al, ep)) return rc;
         done = true;
@@ -762,10 +769,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
-    } else if (w.ndir == 2 && N == 64 && c->opt_fcln64) {     // 16-token tiles, several workgroups per CU (fcln64.hip)
+    } else if (w.ndir == 2 && N == 64 && c->opt_fcln) {     // 16-token tiles, several workgroups per CU (fcln.hip)
+      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, false, false, c->opt_fcln == 2 ? 3 : 2};
       ProfScope ps(c, CAT_FFN, st);
-      const int rc = fcln64_launch(st, 2 * LSTM_H, hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, M, c->num_cus, c->opt_fcln64 == 2 ? 3 : 2);
-      if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln64: %s", hipGetErrorString((hipError_t)rc));
+      const int rc = fcln_launch(st, fa, c->num_cus);
+      if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (fc): %s", hipGetErrorString((hipError_t)rc));
     } else if (w.ndir == 2) {
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -791,7 +799,13 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       ALoadColsReLU al{hc, M, 2 * LSTM_H, 0, BM};
       bool done = false;
       {
-        if (pb.zn2) {
+        if (pb.zn2 && N == 128 && c->opt_fcln) {     // ReLU while loading, 16-token tiles, two workgroups per CU (fcln.hip)
+          FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, pb.zn2, pb.rs2, M, 2 * LSTM_H, N, true, true, 2};
+          ProfScope ps(c, CAT_FFN, st);
+          const int rc = fcln_launch(st, fa, c->num_cus);
+          if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
+          done = true;
+        } else if (pb.zn2) {
           EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
           if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
           done = true;
@@ -2539,7 +2553,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "deterministic") h->opt_deterministic = value != 0;
   else if (k == "pack_wih") h->opt_pack_wih = value != 0;
   else if (k == "fuse_pre") h->opt_fuse_pre = value != 0;
-  else if (k == "fcln64" && value >= 0 && value <= 2) h->opt_fcln64 = value;
+  else if (k == "fcln" && value >= 0 && value <= 2) h->opt_fcln = value;
   else if (k == "fuse_pre128" && value >= 0 && value <= 2) h->opt_fuse_pre128 = value;
   else if (k == "pack_whh") h->opt_pack_whh = value != 0;
   else if (k == "lstm16") h->opt_lstm16 = value != 0;

@@ -44,6 +44,7 @@ VARIANTS = {
     "dptn128_lstm16x": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 0, "fuse_pre128": 2}, 5, 8000, 13, 0),   # input projection inside the recurrence
     "dptn128_pre": (_cfg(DPTN_AV, num_blocks=2), {"lstm4": 0, "fuse_pre128": 0}, 5, 8000, 13, 0),      # ... and the K4 + lstm16 path
     "dptn128_unfused": (_cfg(DPTN_AV, num_blocks=2), {"fuse_attn": 0, "fold_tail": 0, "pack_wih": 0, "pack_whh": 0}, 4, 6000, 7, 2),
+    "dptn128_fc_engine": (_cfg(DPTN_AV, num_blocks=2), {"fcln": 0}, 4, 6000, 7, 2),    # training forward: out-projection / FFN + LayerNorm tape by the GEMM engine (default: fcln.hip)
     "dptn128_long": (_cfg(DPTN_AV, num_blocks=1), {}, 2, 48000, 50, 1),          # inter-chunk sequences > 160: streaming attention
     "dptn64": (_cfg(DPTN_AUDIO, num_blocks=2), {}, 5, 8000, 1, 3),
     "dptn64_lstm4": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 2}, 3, 5000, 1, 2),
@@ -52,8 +53,8 @@ VARIANTS = {
     "dprnn": (_cfg(DPRNN_AV, num_blocks=2), {}, 3, 4000, 9, 2),
     "dprnn_lstm32": (_cfg(DPRNN_AV, num_blocks=2), {"lstm16": 0, "lstm4": 0}, 3, 4000, 9, 2),
     "dprnn_lstm16x": (_cfg(DPRNN_AV, num_blocks=2), {"lstm4": 0}, 3, 4000, 9, 0),
-    "dprnn_fcln3": (_cfg(DPRNN_AV, num_blocks=2), {"fcln64": 2}, 3, 4000, 9, 0),              # fcln64.hip, two tiles ahead (default: one)
-    "dprnn_fc_engine": (_cfg(DPRNN_AV, num_blocks=2), {"fcln64": 0}, 3, 4000, 9, 0),          # ... and the GEMM engine's fc + LayerNorm
+    "dprnn_fcln3": (_cfg(DPRNN_AV, num_blocks=2), {"fcln": 2}, 3, 4000, 9, 0),              # fcln.hip, two tiles ahead (default: one)
+    "dprnn_fc_engine": (_cfg(DPRNN_AV, num_blocks=2), {"fcln": 0}, 3, 4000, 9, 0),          # ... and the GEMM engine's fc + LayerNorm
     "unidir128": (_cfg(DPTN_AV, num_blocks=2, bidir=False), {}, 5, 8000, 13, 3),
     "unidir64": (_cfg(DPTN_AUDIO, num_blocks=2, bidir=False), {}, 4, 8000, 1, 2),
     "split_bf16": (_cfg(DPTN_AV, num_blocks=2), {"split_bf16": 1}, 5, 8000, 13, 0),

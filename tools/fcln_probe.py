@@ -1,5 +1,5 @@
 """fc + LayerNorm + residual of the DPRNN blocks (BASELINE configs[4] head, B = 32 x 128000 samples): time of the launches per
-forward with the dedicated kernel (option fcln64 = 1 / 2) and with the GEMM engine (0), serialised launches (option
+forward with the dedicated kernel (option fcln = 1 / 2) and with the GEMM engine (0), serialised launches (option
 serialize), same process.   python3 tools/fcln_probe.py"""
 import os
 import sys
@@ -19,7 +19,7 @@ args = (t["mix"], t.get("s1_embedding"), t.get("s2_embedding"))
 eng.set_option("serialize", 1)
 for rnd in range(2):
     for v in (0, 1, 2):
-        eng.set_option("fcln64", v)
+        eng.set_option("fcln", v)
         for _ in range(2):
             eng.forward(*args)
         eng.profile(True)
@@ -29,4 +29,4 @@ for rnd in range(2):
         torch.cuda.synchronize()
         rows = eng.profile_read()
         eng.profile(False)
-        print(f"fcln64={v}  " + "  ".join(f"{k}: {ms / 3:.3f} ms / {n // 3}" for k, (ms, n) in rows.items() if n), flush=True)
+        print(f"fcln={v}  " + "  ".join(f"{k}: {ms / 3:.3f} ms / {n // 3}" for k, (ms, n) in rows.items() if n), flush=True)

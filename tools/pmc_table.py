@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_separation_amd.build import source_digest  # noqa: E402  (the tree the profiled command ran from)
 
 # kernels whose global reads are 16 B per lane (float4 / global_load_lds dwordx4) -- the gfx950 half-count applies to them
-WIDE_READERS = ("lstm16_kernel", "lstm16x", "lstm16s_kernel", "lstm32s_kernel", "lstm_recurrence_kernel", "lstm_bptt", "gemm_ws_kernel", "fcln64_kernel", "attn_block",
+WIDE_READERS = ("lstm16_kernel", "lstm16x", "lstm16s_kernel", "lstm32s_kernel", "lstm_recurrence_kernel", "lstm_bptt", "gemm_ws_kernel", "fcln_kernel", "attn_block",
                 "attention_kernel", "attention_long_kernel", "attention_bwd_kernel", "wgrad", "taps_fold_kernel", "attn_pack_kernel",
                 "slab_reduce_frag_kernel", "grad_add_kernel", "adamw_kernel", "grad_clip", "pit_", "sisnr", "fold_decoder_kernel")
 
