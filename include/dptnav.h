@@ -279,7 +279,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *                 residual (dprnn.py:41-45, 83-87); 1 = one tile ahead, three workgroups per CU, 2 = two ahead, two per CU.
  *                 B = 32 x 16 s: 1.25 / 1.21 vs 1.64 ms per launch alone on the chip, 327.1 / 327.8 vs 332.6 ms per forward;
  *                 (b) the training forward with num_features = 128: out-projection + LayerNorm 1 and ReLU -> Linear +
- *                 LayerNorm 2 (dptn.py:46-47, 50-51) with the LayerNorm tape.  Same sums in another order (> 100 dB to 0).
+ *                 LayerNorm 2 (dptn.py:46-47, 50-51) with the LayerNorm tape;
+ *                 (c) inference, DPTN: Linear + LayerNorm 2 of a path whose FFN does not ride in the next attention block (the last
+ *                 one of a forward), and the separation conv behind PReLU (dptn_wav.py:26-29, 47; no LayerNorm) in every
+ *                 forward, 64 and 128 features.  Same sums in another order (> 100 dB to 0).
  *   "pack_whh" (0/1, default 1): the low-latency recurrence (lstm4) reads W_hh from a fragment-order copy made at its
  *                 first launch of a pass; bit-identical to 0.
  *   "lstm4" (0/1/2, default 1): the LOW-LATENCY recurrence on 4-sequence tiles (lstm4.hip, v_mfma_f32_4x4x1_16B_f32; a

@@ -640,7 +640,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     bool done = false;
     {
       if (pb.train && pb.zn1 && N == 128 && c->opt_fcln) {   // 16-token tiles, three workgroups per CU (fcln.hip)
-        FclnArgs fa{att, w.out_w, w.out_b, w.ln1_w, w.ln1_b, x_in, y1, pb.zn1, pb.rs1, M, N, N, true, false, 2};
+        FclnArgs fa{att, w.out_w, w.out_b, w.ln1_w, w.ln1_b, x_in, y1, pb.zn1, pb.rs1, M, N, N, /*pre_res*/ true, /*act*/ 0};
         ProfScope ps(c, CAT_OUTPROJ, st);
         const int rc = fcln_launch(st, fa, c->num_cus);
         if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (out-projection): %s", hipGetErrorString((hipError_t)rc));
@@ -770,7 +770,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
     } else if (w.ndir == 2 && N == 64 && c->opt_fcln) {     // 16-token tiles, several workgroups per CU (fcln.hip)
-      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, false, false, c->opt_fcln == 2 ? 3 : 2};
+      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ false, /*act*/ 0, c->opt_fcln == 2 ? 3 : 2};
       ProfScope ps(c, CAT_FFN, st);
       const int rc = fcln_launch(st, fa, c->num_cus);
       if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (fc): %s", hipGetErrorString((hipError_t)rc));
@@ -800,7 +800,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       bool done = false;
       {
         if (pb.zn2 && N == 128 && c->opt_fcln) {     // ReLU while loading, 16-token tiles, two workgroups per CU (fcln.hip)
-          FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, pb.zn2, pb.rs2, M, 2 * LSTM_H, N, true, true, 2};
+          FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, pb.zn2, pb.rs2, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act: ReLU*/ 1};
           ProfScope ps(c, CAT_FFN, st);
           const int rc = fcln_launch(st, fa, c->num_cus);
           if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
@@ -813,6 +813,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       }
       if (!done)
         if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+    } else if (w.ndir == 2 && c->opt_fcln) {       // (the paths whose FFN does not ride in the next attention block; hc = ReLU(h) already)
+      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act*/ 0};
+      ProfScope ps(c, CAT_FFN, st);
+      const int rc = fcln_launch(st, fa, c->num_cus);
+      if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
     } else if (w.ndir == 2) {
       ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
@@ -869,7 +874,13 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
   float *Z = Zbuf ? Zbuf : ws + pl.qkv, *D = ws + pl.att;
   const int64_t M = pl.M;
   // T1: Z = PReLU(x) W_sep^T + b_sep                            (dptn_wav.py:26-29,47)
-  {
+  if (c->opt_fcln) {       // 16-token tiles, W_sep in registers, two or more workgroups per CU (fcln.hip, its plain form)
+    FclnArgs fa{x, c->w("dprnn.speakers_separation.1.weight"), c->w("dprnn.speakers_separation.1.bias"), nullptr, nullptr, nullptr, Z, nullptr,
+                nullptr, M, N, 2 * N, /*pre_res*/ false, /*act: PReLU*/ 2, 2, /*layernorm*/ false, c->w("dprnn.speakers_separation.0.weight")};
+    ProfScope ps(c, CAT_SEP, st);
+    const int rc = fcln_launch(st, fa, c->num_cus);
+    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (separation conv): %s", hipGetErrorString((hipError_t)rc));
+  } else {
     ALoadDensePReLU al{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
     EpiBiasStore ep{Z, c->w("dprnn.speakers_separation.1.bias"), M, 2 * N, 32, 2 * N};
     if (int rc = launch_gemm<N, N / 64, 1, 4>(c, run, CAT_SEP, "separation gemm",

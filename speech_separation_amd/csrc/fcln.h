@@ -2,12 +2,14 @@
 //
 //   pre_res = 0:  out = LayerNorm(A W^T + bias) * gamma + beta + res      DPRNN blocks: fc (256 -> 64), dprnn.py:41-45, 83-87
 //   pre_res = 1:  out = LayerNorm(A W^T + bias + res) * gamma + beta      DPTN: out-projection + LN1 (dptn.py:46-47), FFN + LN2 (:50-51)
-//   relu_a      :  A is read through ReLU (the DPTN ffn = ReLU -> Linear on the raw h rows the training tape keeps)
+//   layernorm=0:  out = act(A) W^T + bias                                   separation conv: PReLU -> Conv2d(N, 2N, 1), dptn_wav.py:26-29, 47
+//   act         :  A is read through nothing (0), ReLU (1: the DPTN ffn = ReLU -> Linear on the raw h rows the training tape keeps) or
+//                  PReLU with the shared slope *act_w (2)
 //   zn / rstd   :  (both or neither) the normalised rows [M][nout] and 1/sigma [M] for the LayerNorm backward (training tape)
 //
-// A [M][kin], W [nout][kin] (nn.Linear layout), res / out / zn [M][nout].  Shapes taken: (kin, nout) = (256, 64) inference form,
-// (256, 128) and (128, 128) with the tape.  Returns a hipError_t as int; hipErrorInvalidValue for anything else (the caller then
-// uses the GEMM engine).
+// A [M][kin], W [nout][kin] (nn.Linear layout), res / out / zn [M][nout].  Shapes taken (kin -> nout): 256 -> 64 (both residual
+// orders), 256 -> 128 (with / without ReLU + tape), 128 -> 128 with the tape, and the plain forms 128 -> 256, 64 -> 128 behind
+// PReLU.  Returns a hipError_t as int; hipErrorInvalidValue for anything else (the caller then uses the GEMM engine).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -24,7 +26,10 @@ struct FclnArgs {
   float* rstd = nullptr;
   int64_t M = 0;
   int kin = 0, nout = 0;
-  bool pre_res = false, relu_a = false;
-  int nbuf = 2;          // token tiles in flight per workgroup + 1 (nout = 64 only: 2 = three workgroups per CU, 3 = two)
+  bool pre_res = false;
+  int act = 0;
+  int nbuf = 2;          // token tiles in flight per workgroup + 1 (256 -> 64 without pre_res only: 2 = three workgroups per CU, 3 = two)
+  bool layernorm = true;
+  const float* act_w = nullptr;
 };
 int fcln_launch(void* stream, const FclnArgs& a, int num_cus);

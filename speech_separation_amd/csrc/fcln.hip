@@ -1,7 +1,8 @@
 // fcln.hip -- a Linear layer with its LayerNorm and residual on 16-token tiles (gfx950); the forms are listed in fcln.h:
 //     DPRNN blocks         out = LayerNorm(h W_fc^T + b) + x                      src/model/dprnn.py:41-45, 83-87   (256 -> 64)
-//     DPTN, training tape  y1  = LayerNorm1(att W_o^T + b_o + x)                  src/model/dptn.py:46-47            (128 -> 128)
-//                          out = LayerNorm2(ReLU(h) W_f^T + b_f + y1)             src/model/dptn.py:50-51            (256 -> 128)
+//     DPTN                 y1  = LayerNorm1(att W_o^T + b_o + x)                  src/model/dptn.py:46-47            (128 -> 128, tape)
+//                          out = LayerNorm2(ReLU(h) W_f^T + b_f + y1)             src/model/dptn.py:50-51            (256 -> N)
+//     separation conv      Z   = PReLU(x) W_sep^T + b_sep   (no LayerNorm)        src/model/dptn_wav.py:26-29, 47    (N -> 2 N)
 //
 // Why a kernel of its own: in the weights-stationary engine (gemm_ws.h) these launches run ONE workgroup per CU
 // (64- or 32-token tiles double-buffered in LDS), one wave per SIMD, and nothing covers the staging, the barriers and the row-space
@@ -38,21 +39,24 @@ static __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-template <int KIN, int NOUT, int NBUF, bool RELU, bool PRE, bool SAVE>
+// ACT: what A is read through (0 nothing, 1 ReLU, 2 PReLU with the shared slope *act_w); LN: LayerNorm + residual epilogue (else
+// bias + store: no residual tile is fetched); PRE: the residual goes in before the LayerNorm; SAVE: normalised rows + 1/sigma out
+template <int KIN, int NOUT, int NBUF, int ACT, bool LN, bool PRE, bool SAVE>
 __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ res,
-                                                    float* __restrict__ out, float* __restrict__ zn_out, float* __restrict__ rstd_out,
-                                                    int64_t M, int ntiles) {
-  static_assert((KIN == 256 || KIN == 128) && (NOUT == 64 || NOUT == 128), "shapes of the DPRNN / DPTN blocks");
+                                                    const float* __restrict__ act_w, float* __restrict__ out,
+                                                    float* __restrict__ zn_out, float* __restrict__ rstd_out, int64_t M, int ntiles) {
+  static_assert((KIN == 256 || KIN == 128 || KIN == 64) && (NOUT == 64 || NOUT == 128 || NOUT == 256), "shapes of the DPRNN / DPTN blocks");
+  static_assert(LN || (!PRE && !SAVE), "the plain epilogue has no residual and no tape");
   constexpr int MK = KIN / 16;                      // k-chunks of 16
   constexpr int NB = NOUT / 64;                     // 16-column blocks per wave = 64-column segments per row
   constexpr int LDC = NOUT + 4;
   constexpr int TILE = 16 * KIN;                    // floats per staged token tile (unpadded, swizzled)
-  constexpr int RT = 16 * NOUT;                     // floats per residual tile
+  constexpr int RT = LN ? 16 * NOUT : 0;            // floats per residual tile
   constexpr int CPR = KIN / 4;                      // 16-byte chunks per token row
   constexpr int RPR = 256 / KIN;                    // token rows per 1-KiB request
-  constexpr int AREQ = KIN / 64, RREQ = NOUT / 64;  // requests per lane and tile
+  constexpr int AREQ = KIN / 64, RREQ = LN ? NOUT / 64 : 0;  // requests per lane and tile
   constexpr int NREQ = AREQ + RREQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                                 // [NBUF][16][KIN]
@@ -74,13 +78,16 @@ __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, 
       wf[bb][4 * m + 0] = t.x; wf[bb][4 * m + 1] = t.y; wf[bb][4 * m + 2] = t.z; wf[bb][4 * m + 3] = t.w;
     }
   }
-  float4 bc[NB], ga[NB], be[NB];
+  float4 bc[NB], ga[LN ? NB : 1], be[LN ? NB : 1];
 #pragma unroll
   for (int s = 0; s < NB; ++s) {
     bc[s] = *reinterpret_cast<const float4*>(bias + 64 * s + 4 * c4);
-    ga[s] = *reinterpret_cast<const float4*>(gamma + 64 * s + 4 * c4);
-    be[s] = *reinterpret_cast<const float4*>(beta + 64 * s + 4 * c4);
+    if (LN) {
+      ga[s] = *reinterpret_cast<const float4*>(gamma + 64 * s + 4 * c4);
+      be[s] = *reinterpret_cast<const float4*>(beta + 64 * s + 4 * c4);
+    }
   }
+  const float slope = ACT == 2 ? *act_w : 0.f;      // nn.PReLU(): one slope for all channels
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the hand-counted requests below
 
   // ---- staging: tile t -> buffer b.  Wave w fetches token rows 4 w .. 4 w + 3 (1 KiB per request: one row at K = 256, two at
@@ -134,16 +141,20 @@ __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, 
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[bb][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     const float* ab = As + b * TILE + alane;
+    constexpr int MB = MK < 8 ? MK : 8;            // fragment reads in flight
 #pragma unroll
-    for (int m0 = 0; m0 < MK; m0 += 8) {
-      float4 af[8];
+    for (int m0 = 0; m0 < MK; m0 += MB) {
+      float4 af[MB];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < MB; ++m) {
         af[m] = *reinterpret_cast<const float4*>(ab + 16 * (((m0 + m) & 3) ^ aq) + 64 * ((m0 + m) >> 2));
-        if (RELU) af[m] = make_float4(fmaxf(af[m].x, 0.f), fmaxf(af[m].y, 0.f), fmaxf(af[m].z, 0.f), fmaxf(af[m].w, 0.f));
+        if (ACT == 1) af[m] = make_float4(fmaxf(af[m].x, 0.f), fmaxf(af[m].y, 0.f), fmaxf(af[m].z, 0.f), fmaxf(af[m].w, 0.f));
+        if (ACT == 2)     // max(x, 0) + slope * min(x, 0)
+          af[m] = make_float4(fmaf(slope, fminf(af[m].x, 0.f), fmaxf(af[m].x, 0.f)), fmaf(slope, fminf(af[m].y, 0.f), fmaxf(af[m].y, 0.f)),
+                              fmaf(slope, fminf(af[m].z, 0.f), fmaxf(af[m].z, 0.f)), fmaf(slope, fminf(af[m].w, 0.f), fmaxf(af[m].w, 0.f)));
       }
 #pragma unroll
-      for (int m = 0; m < 8; ++m)
+      for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
           acc[bb][0] = mfma16(af[m].x, wf[bb][4 * (m0 + m) + 0], acc[bb][0]);
@@ -159,9 +170,11 @@ __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cs[(4 * ks + r) * LDC + (NOUT / 4) * w + 16 * bb + i16] = s[r];
     }
-    float4 rs[NB];
+    float4 rs[LN ? NB : 1];
+    if (LN) {
 #pragma unroll
-    for (int s = 0; s < NB; ++s) rs[s] = *reinterpret_cast<const float4*>(Rs + b * RT + rrow * NOUT + 64 * s + 4 * c4);
+      for (int s = 0; s < NB; ++s) rs[s] = *reinterpret_cast<const float4*>(Rs + b * RT + rrow * NOUT + 64 * s + 4 * c4);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // Cs complete; every wave is done with buffer b
     {
       const int64_t t = (int64_t)tile + (int64_t)NBUF * G;
@@ -170,7 +183,17 @@ __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, 
 
     // ---- row space: bias (+ residual), LayerNorm over the row's NOUT columns (16 adjacent lanes), (+ residual), store ---------
     // (the next write of Cs is behind the next iteration's first barrier)
-    {
+    if (!LN) {
+      const int64_t tok = (int64_t)tile * 16 + rrow;
+      if (tok < M) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+          const float4 cv = *reinterpret_cast<const float4*>(&Cs[rrow * LDC + 64 * s + 4 * c4]);
+          const f32x2 lo = (f32x2){cv.x, cv.y} + (f32x2){bc[s].x, bc[s].y}, hi = (f32x2){cv.z, cv.w} + (f32x2){bc[s].z, bc[s].w};
+          *reinterpret_cast<float4*>(out + tok * NOUT + 64 * s + 4 * c4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+    } else {
       const int64_t tok = (int64_t)tile * 16 + rrow;
       f32x2 lo[NB], hi[NB];
       f32x2 t = (f32x2){0.f, 0.f};
@@ -217,10 +240,10 @@ __global__ __launch_bounds__(256) void fcln_kernel(const float* __restrict__ A, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup retires
 }
 
-template <int KIN, int NOUT, int NBUF, bool RELU, bool PRE, bool SAVE>
+template <int KIN, int NOUT, int NBUF, int ACT, bool LN, bool PRE, bool SAVE>
 int launch(hipStream_t st, const FclnArgs& a, int num_cus) {
-  auto kern = fcln_kernel<KIN, NOUT, NBUF, RELU, PRE, SAVE>;
-  const size_t lds = sizeof(float) * ((size_t)NBUF * 16 * (KIN + NOUT) + 16 * (NOUT + 4));
+  auto kern = fcln_kernel<KIN, NOUT, NBUF, ACT, LN, PRE, SAVE>;
+  const size_t lds = sizeof(float) * ((size_t)NBUF * 16 * (KIN + (LN ? NOUT : 0)) + 16 * (NOUT + 4));
   static PerDeviceOnce ready;          // (per instantiation)
   static std::atomic<int> per_cu{1};
   const int dev = current_hip_device();
@@ -236,7 +259,8 @@ int launch(hipStream_t st, const FclnArgs& a, int num_cus) {
   const int ntiles = (int)((a.M + 15) / 16);
   const int wgs = per_cu.load() * (num_cus > 0 ? num_cus : 256);
   const int grid = ntiles < wgs ? ntiles : wgs;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a.A, a.W, a.bias, a.gamma, a.beta, a.res, a.out, a.zn, a.rstd, a.M, ntiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a.A, a.W, a.bias, a.gamma, a.beta, a.res, a.act_w, a.out, a.zn, a.rstd, a.M,
+                     ntiles);
   return (int)hipGetLastError();
 }
 
@@ -246,9 +270,17 @@ int fcln_launch(void* stream, const FclnArgs& a, int num_cus) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.M < 1 || (a.M + 15) / 16 > (1 << 27) || (a.zn == nullptr) != (a.rstd == nullptr)) return (int)hipErrorInvalidValue;
   const bool save = a.zn != nullptr;
-  if (a.kin == 256 && a.nout == 64 && !a.pre_res && !a.relu_a && !save)
-    return a.nbuf == 3 ? launch<256, 64, 3, false, false, false>(st, a, num_cus) : launch<256, 64, 2, false, false, false>(st, a, num_cus);
-  if (a.kin == 256 && a.nout == 128 && a.pre_res && a.relu_a && save) return launch<256, 128, 2, true, true, true>(st, a, num_cus);
-  if (a.kin == 128 && a.nout == 128 && a.pre_res && !a.relu_a && save) return launch<128, 128, 2, false, true, true>(st, a, num_cus);
+  if (!a.layernorm) {                                            // separation conv: PReLU -> Linear(N -> 2 N)
+    if (a.act != 2 || a.act_w == nullptr || a.pre_res || save) return (int)hipErrorInvalidValue;
+    if (a.kin == 128 && a.nout == 256) return launch<128, 256, 2, 2, false, false, false>(st, a, num_cus);
+    if (a.kin == 64 && a.nout == 128) return launch<64, 128, 2, 2, false, false, false>(st, a, num_cus);
+    return (int)hipErrorInvalidValue;
+  }
+  if (a.kin == 256 && a.nout == 64 && !a.pre_res && a.act == 0 && !save)
+    return a.nbuf == 3 ? launch<256, 64, 3, 0, true, false, false>(st, a, num_cus) : launch<256, 64, 2, 0, true, false, false>(st, a, num_cus);
+  if (a.kin == 256 && a.nout == 128 && a.pre_res && a.act == 1 && save) return launch<256, 128, 2, 1, true, true, true>(st, a, num_cus);
+  if (a.kin == 128 && a.nout == 128 && a.pre_res && a.act == 0 && save) return launch<128, 128, 2, 0, true, true, true>(st, a, num_cus);
+  if (a.kin == 256 && a.nout == 128 && a.pre_res && a.act == 0 && !save) return launch<256, 128, 2, 0, true, true, false>(st, a, num_cus);
+  if (a.kin == 256 && a.nout == 64 && a.pre_res && a.act == 0 && !save) return launch<256, 64, 2, 0, true, true, false>(st, a, num_cus);
   return (int)hipErrorInvalidValue;      // (other shapes: the GEMM engine)
 }

@@ -49,6 +49,7 @@ VARIANTS = {
     "dptn64": (_cfg(DPTN_AUDIO, num_blocks=2), {}, 5, 8000, 1, 3),
     "dptn64_lstm4": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 2}, 3, 5000, 1, 2),
     "dptn64_lstm16x": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 0}, 5, 8000, 1, 3),          # input projection inside the recurrence
+    "dptn64_fc_engine": (_cfg(DPTN_AUDIO, num_blocks=2), {"fcln": 0}, 3, 5000, 1, 2),          # last FFN + LN2 / separation conv by the GEMM engine (default: fcln.hip)
     "dptn64_pre": (_cfg(DPTN_AUDIO, num_blocks=2), {"lstm4": 0, "fuse_pre": 0}, 3, 5000, 1, 0),  # ... and the K4 + lstm16 path
     "dprnn": (_cfg(DPRNN_AV, num_blocks=2), {}, 3, 4000, 9, 2),
     "dprnn_lstm32": (_cfg(DPRNN_AV, num_blocks=2), {"lstm16": 0, "lstm4": 0}, 3, 4000, 9, 2),
