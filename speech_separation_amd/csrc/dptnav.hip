@@ -104,7 +104,7 @@ struct dptnav_ctx {
   bool opt_ln_tape = true;          // training: LayerNorm backward from zn / rstd left on the tape instead of a recomputed GEMM
   bool opt_fuse_ffn = true;         // ... and K6 of a path as the prologue of the next path's block (dptnav_forward only)
   int opt_lstm_diag = 0;
-  int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine launch from now on returns an error (tests)
+  int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine / fcln launch from now on returns an error (tests)
   bool opt_debug_sync = false;      // debugging aid: name every launch class on stderr and synchronise behind it
   bool opt_train_fuse_probe = false;   // MEASUREMENT ONLY (tools/train_fuse_probe.py): the training forward runs the inference attention block
                                        // (no qkv / att / LayerNorm tape: a backward after it is garbage) -- the upper bound of a fused front half
@@ -219,6 +219,8 @@ namespace {
 inline size_t align64(size_t nfloats) { return (nfloats + 63) & ~(size_t)63; }
 
 // Opt-in per-kernel timing: HIP events recorded on the launch stream around one launch.
+// fault injection for the error-path tests (option "inject_fail"): the n-th launch of the GEMM engine / of fcln.hip from now on fails
+static int inject_failure(dptnav_ctx* c, const char* what);
 struct ProfScope {
   dptnav_ctx* c;
   hipStream_t st;
@@ -242,6 +244,11 @@ struct ProfScope {
     c->prof_pending.push_back(rec);
   }
 };
+
+static int inject_failure(dptnav_ctx* c, const char* what) {
+  if (c->opt_inject_fail > 0 && --c->opt_inject_fail == 0) return c->fail(DPTNAV_ERR_INVALID, "%s: injected failure", what);
+  return DPTNAV_OK;
+}
 
 void build_names(dptnav_ctx* c) {
   const dptnav_config& g = c->cfg;
@@ -457,8 +464,7 @@ int launch_gemm(dptnav_ctx* c, Run& run, int cat, const char* what, const float*
                 const AL& al, const EP& ep, const float* Walt = nullptr, int ldw = KIN, int* grid_used = nullptr,
                 const RD& rider = RD{}) {
   hipStream_t st = run.st;
-  if (c->opt_inject_fail > 0 && --c->opt_inject_fail == 0)   // fault injection for the error-path tests (option "inject_fail")
-    return c->fail(DPTNAV_ERR_INVALID, "%s: injected failure", what);
+  if (int rc = inject_failure(c, what)) return rc;
   if (run.slot + colgroups > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
   auto kern = gemm_ws_kernel<KIN, NT, WR, WC, AL, EP, WT, SPLIT, RD>;
   const size_t lds = GemmShape<KIN, NT, WR, WC>::lds_bytes(EP::DIRECT, SPLIT, rider_kk<RD>::value * (RD::ON ? 1 : 0));
@@ -641,6 +647,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     {
       if (pb.train && pb.zn1 && N == 128 && c->opt_fcln) {   // 16-token tiles, three workgroups per CU (fcln.hip)
         FclnArgs fa{att, w.out_w, w.out_b, w.ln1_w, w.ln1_b, x_in, y1, pb.zn1, pb.rs1, M, N, N, /*pre_res*/ true, /*act*/ 0};
+        if (int rc = inject_failure(c, "fcln (out-projection)")) return rc;
         ProfScope ps(c, CAT_OUTPROJ, st);
         const int rc = fcln_launch(st, fa, c->num_cus);
         if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (out-projection): %s", hipGetErrorString((hipError_t)rc));
@@ -771,6 +778,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
     } else if (w.ndir == 2 && N == 64 && c->opt_fcln) {     // 16-token tiles, several workgroups per CU (fcln.hip)
       FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ false, /*act*/ 0, c->opt_fcln == 2 ? 3 : 2};
+      if (int rc = inject_failure(c, "fcln (fc)")) return rc;
       ProfScope ps(c, CAT_FFN, st);
       const int rc = fcln_launch(st, fa, c->num_cus);
       if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (fc): %s", hipGetErrorString((hipError_t)rc));
@@ -801,6 +809,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       {
         if (pb.zn2 && N == 128 && c->opt_fcln) {     // ReLU while loading, 16-token tiles, two workgroups per CU (fcln.hip)
           FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, pb.zn2, pb.rs2, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act: ReLU*/ 1};
+          if (int rc = inject_failure(c, "fcln (ffn)")) return rc;
           ProfScope ps(c, CAT_FFN, st);
           const int rc = fcln_launch(st, fa, c->num_cus);
           if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
@@ -815,6 +824,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
         if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
     } else if (w.ndir == 2 && c->opt_fcln) {       // (the paths whose FFN does not ride in the next attention block; hc = ReLU(h) already)
       FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act*/ 0};
+      if (int rc = inject_failure(c, "fcln (ffn)")) return rc;
       ProfScope ps(c, CAT_FFN, st);
       const int rc = fcln_launch(st, fa, c->num_cus);
       if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
@@ -877,6 +887,7 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
   if (c->opt_fcln) {       // 16-token tiles, W_sep in registers, two or more workgroups per CU (fcln.hip, its plain form)
     FclnArgs fa{x, c->w("dprnn.speakers_separation.1.weight"), c->w("dprnn.speakers_separation.1.bias"), nullptr, nullptr, nullptr, Z, nullptr,
                 nullptr, M, N, 2 * N, /*pre_res*/ false, /*act: PReLU*/ 2, 2, /*layernorm*/ false, c->w("dprnn.speakers_separation.0.weight")};
+    if (int rc = inject_failure(c, "fcln (separation conv)")) return rc;
     ProfScope ps(c, CAT_SEP, st);
     const int rc = fcln_launch(st, fa, c->num_cus);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (separation conv): %s", hipGetErrorString((hipError_t)rc));

@@ -23,9 +23,6 @@ __global__ __launch_bounds__(256) void video_linear_kernel(const float* __restri
   for (int t = threadIdx.x & 63; t < Tv; t += 64) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int cc = 0;
-    // (unrolled: 32 embedding loads in flight -- rolled up, every group of four waited out a memory round trip: 50 us for a
-    // 40-MFLOP product at the very start of a forward, when nothing else runs; same chains, same order: bit-identical)
-#pragma unroll 8
     for (; cc + 4 <= Cv; cc += 4) {
       a0 = fmaf(w[cc + 0], e[(int64_t)(cc + 0) * Tv + t], a0);
       a1 = fmaf(w[cc + 1], e[(int64_t)(cc + 1) * Tv + t], a1);
