@@ -380,7 +380,9 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
     flops, ffn_rides = class_flops_per_step(cfg, prof, B, S, eng.frames(T))
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     ndir = 2 if cfg.bidir else 1
-    dprnn_fc = cfg.arch != "dptn" and cfg.num_features == 64 and cfg.bidir       # (option fcln, default on: run_path in dptnav.hip)
+    fcln_on = eng.options_set.get("fcln", 1) != 0                    # (option fcln, default on: run_path / run_tail in dptnav.hip)
+    dprnn_fc = fcln_on and cfg.arch != "dptn" and cfg.num_features == 64 and cfg.bidir
+    fcln_ffn = fcln_on and cfg.arch == "dptn" and cfg.bidir
     rows = []
     for cls, fl in flops.items():
         ms, n = prof.get(cls, (0.0, 0))
@@ -419,13 +421,17 @@ def kernel_rows(cfg, eng, prof, psteps, B, T, dev):
         else:
             row.update(kernel={"lstm_pre_gemm": "gemm_ws_kernel<..., EpiLstmPre*> (x W_ih^T + b, fragment-order store)",
                                "ffn_ln_gemm": "fcln_kernel (DPRNN: LayerNorm(h W_fc^T + b) + x on 16-token tiles)" if dprnn_fc else
-                               "gemm_ws_kernel<..., EpiBiasResLN> (ReLU(h) W_f^T + b + y1, LayerNorm 2)",
+                               ("fcln_kernel (LayerNorm 2 of ReLU(h) W_f^T + b + y1 on 16-token tiles: the paths whose FFN does not ride in "
+                                "the next attention block)" if fcln_ffn else "gemm_ws_kernel<..., EpiBiasResLN> (ReLU(h) W_f^T + b + y1, LayerNorm 2)"),
                                "qkv_gemm": "gemm_ws_kernel<..., EpiBiasStore> (in-projection)",
                                "outproj_ln_gemm": "gemm_ws_kernel<..., EpiBiasResLN> (out-projection + residual + LayerNorm 1)",
-                               "sep_gemm": "gemm_ws_kernel<..., ALoadDensePReLU, EpiBiasStore> (PReLU + 1x1 conv N -> 2N)",
+                               "sep_gemm": "fcln_kernel, plain form (PReLU + 1x1 conv N -> 2N on 16-token tiles)" if fcln_on else
+                               "gemm_ws_kernel<..., ALoadDensePReLU, EpiBiasStore> (PReLU + 1x1 conv N -> 2N)",
                                "postproc_gemm": "taps_fold_kernel (OLA gather + post-processing conv + skip + decoder taps)"}[cls],
-                       pmc_match={"lstm_pre_gemm": "EpiLstmPre", "sep_gemm": "ALoadDensePReLU", "postproc_gemm": "taps_fold_kernel",
-                                  "ffn_ln_gemm": "fcln_kernel" if dprnn_fc else "ALoadColsT<false>, EpiBiasResLN"}.get(cls))
+                       pmc_match={"lstm_pre_gemm": "EpiLstmPre", "postproc_gemm": "taps_fold_kernel",
+                                  "sep_gemm": f"fcln_kernel<{cfg.num_features}, {2 * cfg.num_features}," if fcln_on else "ALoadDensePReLU",
+                                  "ffn_ln_gemm": f"fcln_kernel<256, {cfg.num_features}," if (dprnn_fc or fcln_ffn) else
+                                  "ALoadColsT<false>, EpiBiasResLN"}.get(cls))
         rows.append(row)
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows

@@ -56,6 +56,7 @@ class DptnEngine:
         self.cfg = cfg
         self.device = torch.device(device)
         self._alloc_hook = alloc
+        self.options_set: Dict[str, int] = {}
         if self.device.type != "cuda":
             raise RuntimeError("DptnEngine needs a GPU device (PyTorch-ROCm 'cuda:N'); there is no CPU path")
         if self.device.index is None:
@@ -186,6 +187,7 @@ class DptnEngine:
         rc = self.lib.dptnav_set_option(self._h, key.encode(), int(value))
         if rc:
             self._raise(rc, "dptnav_set_option")
+        self.options_set[key] = int(value)        # what this wrapper has set (the library's defaults are in dptnav.h)
 
     # ------------------------------------------------------------------ per-kernel device timing
     def profile(self, on: bool):
