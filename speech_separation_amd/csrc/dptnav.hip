@@ -857,7 +857,7 @@ int run_head(dptnav_ctx* c, Run& run, const float* mix, const float* e1, const f
   if (!g.audio_only) {
     float* v = vidbuf ? vidbuf : ws + pl.vid;
     ProfScope ps(c, CAT_VIDEO, st);
-    hipLaunchKernelGGL(video_linear_kernel, dim3(2 * B, g.hidden_video / 8), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
+    hipLaunchKernelGGL(video_linear_kernel, dim3(2 * B, g.hidden_video / 2), dim3(256), 0, st, e1, e2, c->w("visual_compression.weight"),
                        c->w("visual_compression.bias"), v, g.video_emb_size, Tv, g.hidden_video / 2);
     LAUNCH_CHECK(c, "video linear");
     vid = v;

@@ -269,6 +269,7 @@ int launch(hipStream_t st, const FclnArgs& a, int num_cus) {
 int fcln_launch(void* stream, const FclnArgs& a, int num_cus) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a.M < 1 || (a.M + 15) / 16 > (1 << 27) || (a.zn == nullptr) != (a.rstd == nullptr)) return (int)hipErrorInvalidValue;
+  if (!a.A || !a.W || !a.bias || !a.out || (a.layernorm && (!a.gamma || !a.beta || !a.res))) return (int)hipErrorInvalidValue;
   const bool save = a.zn != nullptr;
   if (!a.layernorm) {                                            // separation conv: PReLU -> Linear(N -> 2 N)
     if (a.act != 2 || a.act_w == nullptr || a.pre_res || save) return (int)hipErrorInvalidValue;

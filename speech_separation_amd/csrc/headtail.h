@@ -9,28 +9,40 @@
 // video branch, step 1: Linear(Cv -> HV/2) for both speakers (shared weights), concatenated
 //   reference: dptn_wav.py:173-179.   e* (B,Cv,Tv) -> vid (B,Tv,HV)
 // ------------------------------------------------------------------------------------------------
-//   grid (B*2, half/4), block 256 = 4 output features x 64 frame slots: the weight is wave-uniform, the
-//   embedding read is coalesced over frames.
+//   grid (B*2, half), block 256 = ONE output feature: the four waves take a quarter of the Cv input channels each (lanes = frame
+//   slots, the embedding read is coalesced over frames, the weight is wave-uniform) and meet in LDS, summed in a fixed order.
+//   (Four features per workgroup with the whole contraction per wave was 50 us for a 40-MFLOP product: 512 dependent-latency
+//   iterations per wave at the very start of a forward, when nothing else runs.)
 __global__ __launch_bounds__(256) void video_linear_kernel(const float* __restrict__ e1,
                                                             const float* __restrict__ e2,
                                                             const float* __restrict__ W,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ vid, int Cv, int Tv, int half) {
+  __shared__ float part[4][64];
   const int b = blockIdx.x >> 1, spk = blockIdx.x & 1;
-  const int o = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int o = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* e = (spk ? e2 : e1) + (int64_t)b * Cv * Tv;
   const float* w = W + (int64_t)o * Cv;
-  for (int t = threadIdx.x & 63; t < Tv; t += 64) {
+  const int q = (Cv + 3) / 4, c0 = wv * q, c1 = c0 + q < Cv ? c0 + q : Cv;
+  for (int t0 = 0; t0 < Tv; t0 += 64) {
+    const int t = t0 + lane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int cc = 0;
-    for (; cc + 4 <= Cv; cc += 4) {
-      a0 = fmaf(w[cc + 0], e[(int64_t)(cc + 0) * Tv + t], a0);
-      a1 = fmaf(w[cc + 1], e[(int64_t)(cc + 1) * Tv + t], a1);
-      a2 = fmaf(w[cc + 2], e[(int64_t)(cc + 2) * Tv + t], a2);
-      a3 = fmaf(w[cc + 3], e[(int64_t)(cc + 3) * Tv + t], a3);
+    if (t < Tv) {
+      int cc = c0;
+#pragma unroll 8
+      for (; cc + 4 <= c1; cc += 4) {
+        a0 = fmaf(w[cc + 0], e[(int64_t)(cc + 0) * Tv + t], a0);
+        a1 = fmaf(w[cc + 1], e[(int64_t)(cc + 1) * Tv + t], a1);
+        a2 = fmaf(w[cc + 2], e[(int64_t)(cc + 2) * Tv + t], a2);
+        a3 = fmaf(w[cc + 3], e[(int64_t)(cc + 3) * Tv + t], a3);
+      }
+      for (; cc < c1; ++cc) a0 = fmaf(w[cc], e[(int64_t)cc * Tv + t], a0);
     }
-    for (; cc < Cv; ++cc) a0 = fmaf(w[cc], e[(int64_t)cc * Tv + t], a0);
-    vid[((int64_t)b * Tv + t) * (2 * half) + spk * half + o] = ((a0 + a1) + (a2 + a3)) + bias[o];
+    part[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0 && t < Tv)
+      vid[((int64_t)b * Tv + t) * (2 * half) + spk * half + o] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + bias[o];
+    __syncthreads();
   }
 }
 
