@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Concurrency summary of a rocprofv3 kernel timeline (tools/gpu_train_timeline.sh): for the LAST complete step, how long
 0 / 1 / 2 / 3 kernels were in flight, which kernels ran alone, and how long a recurrence (lstm16 / bptt) was the only
-kernel on the chip.   usage: timeline_summary.py <kernel_trace.csv> [train|forward]"""
+kernel on the chip.   usage: timeline_summary.py <kernel_trace.csv> [train|forward [sub-batches per forward]]"""
 import collections
 import csv
 import sys
@@ -19,7 +19,7 @@ if mode == "train":      # a step ends with its AdamW launches
     s0, s1 = ends[-2], ends[-1]
 else:                    # a forward ends with the decoder gathers of its sub-batches
     marks = sorted(e[1] for e in ev if "decoder_gather" in e[2])
-    per = max(1, len(marks) // 4)
+    per = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, len(marks) // 4)      # gathers per forward = its sub-batches
     s0, s1 = marks[-1 - per], marks[-1]
 sel = [e for e in ev if e[0] >= s0 and e[1] <= s1 + 1e6]
 pts = sorted([(a, 1, n) for a, b, n in sel] + [(b, -1, n) for a, b, n in sel])
