@@ -22,6 +22,7 @@ SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "
            "lstm_bptt16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            # attn_block.hip: the softmax works on MFMA results with plain VALU instructions -> accumulators in architectural VGPRs
            "attn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "attn_block2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "attn_block64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm16s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

@@ -34,3 +34,9 @@ int attn_pack_launch(void* stream, const AttnPackSrc* src, int npaths, float* ds
 int attn_block_launch(void* stream, const float* x, const float* w_in, const float* b_in, const float* w_o, const float* b_o,
                       const float* gamma, const float* beta, float* y1, const SeqGeom& g, bool split = false,
                       const AttnFfnPrologue* pro = nullptr, const float* wpack = nullptr);
+
+// attn_block2.hip (round 5): the same block with both LayerNorms in fragment space and the prologue's h rows by LDS-DMA; fp32,
+// packed weights only.  Same arguments, same results up to the grouping of the LayerNorm sums.
+size_t attn_block2_lds_bytes(int nkb, bool pro);
+int attn_block2_launch(void* stream, const float* x, const float* b_in, const float* b_o, const float* gamma, const float* beta,
+                       float* y1, const SeqGeom& g, const AttnFfnPrologue* pro, const float* wpack);

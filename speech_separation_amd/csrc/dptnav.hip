@@ -98,6 +98,7 @@ struct dptnav_ctx {
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_attn_v2 = true;          // ... in the form with both LayerNorms in fragment space and h rows by LDS-DMA (attn_block2.hip)
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
   bool opt_wgrad_ride = true;       // training: out-projection / ffn weight gradients formed inside their data-gradient GEMMs
   bool opt_wgrad2 = true;           // training: LSTM W_ih / W_hh gradients in one pass over dP (wgrad2_kernel)
@@ -106,7 +107,7 @@ struct dptnav_ctx {
   int opt_lstm_diag = 0;
   int opt_inject_fail = 0;          // > 0: the n-th GEMM-engine / fcln launch from now on returns an error (tests)
   bool opt_debug_sync = false;      // debugging aid: name every launch class on stderr and synchronise behind it
-  bool opt_train_fuse_probe = false;   // MEASUREMENT ONLY (tools/train_fuse_probe.py): the training forward runs the inference attention block
+  bool opt_train_fuse_probe = false;   // MEASUREMENT ONLY (no tape is written: dptnav_train_backward / _path_backward refuse while it is set) (tools/train_fuse_probe.py): the training forward runs the inference attention block
                                        // (no qkv / att / LayerNorm tape: a backward after it is garbage) -- the upper bound of a fused front half
   int opt_dropout_ppm = 0;          // train-mode attention dropout probability x 1e6 (0 = off)
   unsigned opt_dropout_seed = 0;
@@ -573,6 +574,21 @@ static int pack_wih_all(dptnav_ctx* c, Run& run) {
   return DPTNAV_OK;
 }
 
+// fcln.hip for one Linear (+ LayerNorm) launch.  Returns 1 when the launch went out, 0 when fcln_launch does not take the shape
+// (hipErrorInvalidValue, fcln.h: the caller then uses the GEMM engine; the sticky error is cleared), a negative DPTNAV error otherwise.
+static int try_fcln(dptnav_ctx* c, hipStream_t st, const FclnArgs& fa, int cat, const char* what) {
+  if (int rc = inject_failure(c, what)) return rc < 0 ? rc : -rc;
+  ProfScope ps(c, cat, st);
+  const int rc = fcln_launch(st, fa, c->num_cus);
+  if (rc == 0) return 1;
+  if (rc == (int)hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+  return e < 0 ? e : -e;
+}
+
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
              const PathBufs* bufs = nullptr, int chain = 0) {
@@ -623,8 +639,10 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       wpack = pk;
       if (chain & CHAIN_PRO) pro.wf = pk - ATTN_PACK_FLOATS + ATTN_PACK_IN + ATTN_PACK_OUT;   // previous path's ffn.1 segment
     }
-    const int rc = attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16,
-                                     (chain & CHAIN_PRO) ? &pro : nullptr, wpack);
+    const int rc = (c->opt_attn_v2 && !c->opt_split_bf16)
+                       ? attn_block2_launch(st, x_in, w.in_b, w.out_b, w.ln1_w, w.ln1_b, y1, geom, (chain & CHAIN_PRO) ? &pro : nullptr, wpack)
+                       : attn_block_launch(st, x_in, w.in_w, w.in_b, w.out_w, w.out_b, w.ln1_w, w.ln1_b, y1, geom, c->opt_split_bf16,
+                                           (chain & CHAIN_PRO) ? &pro : nullptr, wpack);
     if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "attention block: %s", hipGetErrorString((hipError_t)rc));
   } else if (chain & CHAIN_PRO) {
     return c->fail(DPTNAV_ERR_INVALID, "internal: FFN prologue requested for an unfused attention block");
@@ -647,12 +665,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
     {
       if (pb.train && pb.zn1 && N == 128 && c->opt_fcln) {   // 16-token tiles, three workgroups per CU (fcln.hip)
         FclnArgs fa{att, w.out_w, w.out_b, w.ln1_w, w.ln1_b, x_in, y1, pb.zn1, pb.rs1, M, N, N, /*pre_res*/ true, /*act*/ 0};
-        if (int rc = inject_failure(c, "fcln (out-projection)")) return rc;
-        ProfScope ps(c, CAT_OUTPROJ, st);
-        const int rc = fcln_launch(st, fa, c->num_cus);
-        if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (out-projection): %s", hipGetErrorString((hipError_t)rc));
-        done = true;
-      } else if (pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
+        const int r = try_fcln(c, st, fa, CAT_OUTPROJ, "fcln (out-projection)");
+        if (r < 0) return -r;
+        done = r > 0;
+      }
+      if (!done && pb.train && pb.zn1) {   // + zn / rstd on the tape for the LayerNorm backward
         EpiBiasResLNSave<GROUP> ep{y1, w.out_b, x_in, w.ln1_w, w.ln1_b, M, N, BM, pb.zn1, pb.rs1};
         if (int rc = launch_gemm<N, 1, WR, WC>(c, run, CAT_OUTPROJ, "out-proj gemm (tape)", w.out_w, ntiles, 1, al, ep)) return rc;
         done = true;
@@ -776,15 +793,17 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       ALoadDense al{hc, M, 2 * LSTM_H, BM};
       EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
       if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
-    } else if (w.ndir == 2 && N == 64 && c->opt_fcln) {     // 16-token tiles, several workgroups per CU (fcln.hip)
-      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ false, /*act*/ 0, c->opt_fcln == 2 ? 3 : 2};
-      if (int rc = inject_failure(c, "fcln (fc)")) return rc;
-      ProfScope ps(c, CAT_FFN, st);
-      const int rc = fcln_launch(st, fa, c->num_cus);
-      if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (fc): %s", hipGetErrorString((hipError_t)rc));
     } else if (w.ndir == 2) {
-      ALoadDense al{hc, M, 2 * LSTM_H, BM};
-      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+      int r = 0;
+      if (N == 64 && c->opt_fcln) {     // 16-token tiles, several workgroups per CU (fcln.hip)
+        FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, x_in, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ false, /*act*/ 0, c->opt_fcln == 2 ? 3 : 2};
+        r = try_fcln(c, st, fa, CAT_FFN, "fcln (fc)");
+        if (r < 0) return -r;
+      }
+      if (r == 0) {
+        ALoadDense al{hc, M, 2 * LSTM_H, BM};
+        if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "fc gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+      }
     } else if (pb.train && pb.zn2) {
       ALoadDense al{hc, M, LSTM_H, BM};
       EpiBiasLNResSave<GROUP> eps{x_out, w.ffn_b, x_in, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
@@ -809,12 +828,11 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       {
         if (pb.zn2 && N == 128 && c->opt_fcln) {     // ReLU while loading, 16-token tiles, two workgroups per CU (fcln.hip)
           FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, pb.zn2, pb.rs2, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act: ReLU*/ 1};
-          if (int rc = inject_failure(c, "fcln (ffn)")) return rc;
-          ProfScope ps(c, CAT_FFN, st);
-          const int rc = fcln_launch(st, fa, c->num_cus);
-          if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
-          done = true;
-        } else if (pb.zn2) {
+          const int r = try_fcln(c, st, fa, CAT_FFN, "fcln (ffn)");
+          if (r < 0) return -r;
+          done = r > 0;
+        }
+        if (!done && pb.zn2) {
           EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
           if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm (tape)", w.ffn_w, ntiles, 1, al, eps)) return rc;
           done = true;
@@ -822,15 +840,17 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
       }
       if (!done)
         if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
-    } else if (w.ndir == 2 && c->opt_fcln) {       // (the paths whose FFN does not ride in the next attention block; hc = ReLU(h) already)
-      FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act*/ 0};
-      if (int rc = inject_failure(c, "fcln (ffn)")) return rc;
-      ProfScope ps(c, CAT_FFN, st);
-      const int rc = fcln_launch(st, fa, c->num_cus);
-      if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (ffn): %s", hipGetErrorString((hipError_t)rc));
     } else if (w.ndir == 2) {
-      ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
-      if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+      int r = 0;
+      if (c->opt_fcln) {       // (the paths whose FFN does not ride in the next attention block; hc = ReLU(h) already)
+        FclnArgs fa{hc, w.ffn_w, w.ffn_b, w.ln2_w, w.ln2_b, y1, x_out, nullptr, nullptr, M, 2 * LSTM_H, N, /*pre_res*/ true, /*act*/ 0};
+        r = try_fcln(c, st, fa, CAT_FFN, "fcln (ffn)");
+        if (r < 0) return -r;
+      }
+      if (r == 0) {
+        ALoadCols al{hc, M, 2 * LSTM_H, 0, BM};
+        if (int rc = launch_gemm<2 * LSTM_H, 1, WR, WC>(c, run, CAT_FFN, "ffn gemm", w.ffn_w, ntiles, 1, al, ep)) return rc;
+      }
     } else if (pb.train && pb.zn2) {
       ALoadColsReLU al{hc, M, LSTM_H, 0, BM};
       EpiBiasResLNSave<GROUP> eps{x_out, w.ffn_b, y1, w.ln2_w, w.ln2_b, M, N, BM, pb.zn2, pb.rs2};
@@ -884,14 +904,14 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
   float *Z = Zbuf ? Zbuf : ws + pl.qkv, *D = ws + pl.att;
   const int64_t M = pl.M;
   // T1: Z = PReLU(x) W_sep^T + b_sep                            (dptn_wav.py:26-29,47)
+  int sep_done = 0;
   if (c->opt_fcln) {       // 16-token tiles, W_sep in registers, two or more workgroups per CU (fcln.hip, its plain form)
     FclnArgs fa{x, c->w("dprnn.speakers_separation.1.weight"), c->w("dprnn.speakers_separation.1.bias"), nullptr, nullptr, nullptr, Z, nullptr,
                 nullptr, M, N, 2 * N, /*pre_res*/ false, /*act: PReLU*/ 2, 2, /*layernorm*/ false, c->w("dprnn.speakers_separation.0.weight")};
-    if (int rc = inject_failure(c, "fcln (separation conv)")) return rc;
-    ProfScope ps(c, CAT_SEP, st);
-    const int rc = fcln_launch(st, fa, c->num_cus);
-    if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "fcln (separation conv): %s", hipGetErrorString((hipError_t)rc));
-  } else {
+    sep_done = try_fcln(c, st, fa, CAT_SEP, "fcln (separation conv)");
+    if (sep_done < 0) return -sep_done;
+  }
+  if (!sep_done) {
     ALoadDensePReLU al{x, c->w("dprnn.speakers_separation.0.weight"), M, N, 32};
     EpiBiasStore ep{Z, c->w("dprnn.speakers_separation.1.bias"), M, 2 * N, 32, 2 * N};
     if (int rc = launch_gemm<N, N / 64, 1, 4>(c, run, CAT_SEP, "separation gemm",
@@ -2584,6 +2604,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
     h->opt_lstm4 = (int)value;
   }
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
+  else if (k == "attn_v2") h->opt_attn_v2 = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "ln_tape") h->opt_ln_tape = value != 0;

@@ -354,10 +354,16 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
     const int64_t tokb = seq_token_base(g, q < g.nseq ? q : g.nseq - 1);
     xp[i] = reinterpret_cast<const char*>(x) + ((tokb + (int64_t)t0 * tstride) * ldx + 4 * ((lane & 31) ^ (row & 15))) * 4;
   }
+  // Issued as inline assembly ON PURPOSE (fcln.hip has the long version): through __builtin_amdgcn_global_load_lds the compiler knows
+  // that memory -> LDS traffic is outstanding and, unable to tell the buffers apart, puts s_waitcnt vmcnt(0) in front of the NEXT LDS
+  // access -- here the a_next fragment read eleven instructions behind the request, so every step sat out the round trip of the rows
+  // it had just asked for (rounds 4's kernel: line `s_waitcnt vmcnt(0)` right behind the two requests).  The one wait
+  // this traffic needs is written by hand at the end of the step.
+  const uint32_t xs_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)Xs;
   auto dma_x = [&](int s, int buf, int i) {        // x_s -> Xs[buf], this wave's request i
     const int64_t adv = (int64_t)(s < g.len ? s : g.len - 1) * xstep;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + adv),
-                                     (__attribute__((address_space(3))) void*)(Xs + buf * X128_XS_FLOATS + (2 * w + i) * 256), 16, 0, 0);
+    const uint32_t dst = xs_lds + (uint32_t)((buf * X128_XS_FLOATS + (2 * w + i) * 256) * 4);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(xp[i] + adv) : "memory", "m0");
   };
   dma_x(0, 0, 0); dma_x(0, 0, 1);
   dma_x(1, 1, 0); dma_x(1, 1, 1);

@@ -53,14 +53,16 @@ def run_inference(model: Callable[..., Mapping[str, torch.Tensor]], entries: Lis
     import time
     from concurrent.futures import ThreadPoolExecutor
 
-    from .io import PinnedBatcher, PredictionWriter, load_item
+    from .io import PinnedBatcher, PredictionWriter, load_item, save_predictions
     env = env or DistEnv(0, 0, 1, torch.device(device), None)
     dev = env.device
     nb = (len(entries) + batch_size - 1) // batch_size
     lo, hi = shard_range(nb, env.rank, env.world)
     mine = [entries[b * batch_size:(b + 1) * batch_size] for b in range(lo, hi)]
     batcher = PinnedBatcher(dev)
-    writer = PredictionWriter(dev) if save_dir is not None else None
+    cuda = dev.type == "cuda"          # (a CPU device only exists for the host-logic rehearsals in tests/: gloo ranks, a stand-in model)
+    writer = PredictionWriter(dev) if save_dir is not None and cuda else None
+    cpu_paths: List[str] = []
     sums = [0.0] * len(metrics)
     met_means = []        # per batch: the metrics' device-side means (read once, after the loop: no stall per batch)
     n_items = 0
@@ -82,12 +84,15 @@ def run_inference(model: Callable[..., Mapping[str, torch.Tensor]], entries: Lis
                         sums[j] += float(met(**batch))
             if writer is not None:
                 writer.submit(batch, save_dir)                  # inferencer.py:128-147
+            elif save_dir is not None:
+                cpu_paths += save_predictions(batch, save_dir)
             n_items += len(items)
     for per_batch in met_means:
         for j, (met, means) in enumerate(zip(metrics, per_batch)):
             sums[j] += float(met.resolve(means.cpu()))
-    paths = writer.close() if writer is not None else []
-    torch.cuda.synchronize(dev)
+    paths = writer.close() if writer is not None else cpu_paths
+    if cuda:
+        torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     tot = env.sum_over_ranks(sums + [float(hi - lo)])
     logs = {met.name: tot[j] / max(tot[-1], 1.0) for j, met in enumerate(metrics)}

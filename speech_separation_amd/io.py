@@ -264,3 +264,42 @@ class PredictionWriter:
         if self._error is not None:
             raise self._error
         return self._paths
+
+
+# ---- the inverse of the loaders: a dataset in the reference's on-disk formats (bench.py's end-to-end leg, tests) ----------------
+def write_wav(path: str, x, sr: int = 8000):
+    """Mono PCM16 WAV of x in [-1, 1); returns the quantised samples as float32 (what load_audio reads back)."""
+    import wave
+    pcm = np.clip(np.round(np.asarray(x) * 32768.0), -32768, 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(pcm.tobytes())
+    return pcm.astype(np.float32) / 32768.0
+
+
+def write_synthetic_dataset(root: str, n: int, T: int, Tv: int = 50, emb: int = 512, sr: int = 8000, seed: int = 0):
+    """n items under root/{mix,s1,s2,emb}: PCM16 WAVs of two noise sources and their sum, and the two lip embeddings as
+    ``np.savez_compressed(embedding=(emb, Tv) f32)`` (make_embeddings.py:69), plus the index entries BaseDataset.__getitem__
+    consumes (base_dataset.py:70-98).  Returns (entries, truth): truth holds what the loaders must read back."""
+    rng = np.random.default_rng(seed)
+    for d in ("mix", "s1", "s2", "emb"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    entries, truth = [], []
+    for i in range(n):
+        s1 = 0.1 * rng.standard_normal(T)
+        s2 = 0.1 * rng.standard_normal(T)
+        paths = {k: os.path.join(root, k, f"utt{i:04d}.wav") for k in ("mix", "s1", "s2")}
+        q = {"s1": write_wav(paths["s1"], s1, sr), "s2": write_wav(paths["s2"], s2, sr)}
+        q["mix"] = write_wav(paths["mix"], s1 + s2, sr)
+        e = {}
+        for k in ("s1", "s2"):
+            e[k] = rng.standard_normal((emb, Tv)).astype(np.float32)
+            np.savez_compressed(os.path.join(root, "emb", f"utt{i:04d}_{k}.npz"), embedding=e[k])
+        entries.append({"mix_wav_path": paths["mix"], "s1_wav_path": paths["s1"], "s2_wav_path": paths["s2"],
+                        "s1_video_path": None, "s2_video_path": None,
+                        "s1_embedding_path": os.path.join(root, "emb", f"utt{i:04d}_s1.npz"),
+                        "s2_embedding_path": os.path.join(root, "emb", f"utt{i:04d}_s2.npz")})
+        truth.append({**q, "s1_embedding": e["s1"], "s2_embedding": e["s2"]})
+    return entries, truth
