@@ -74,11 +74,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-PMC_TABLES = {"dptn_av": os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"),
-              "dptn_audio": os.path.join(ROOT, "profiles", "r04_pmc_traffic_dptn_audio.json"),
-              "dprnn_av": os.path.join(ROOT, "profiles", "r04_pmc_traffic_dprnn_av.json")}
+PMC_TABLES = {"dptn_av": os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"),
+              "dptn_audio": os.path.join(ROOT, "profiles", "r05_pmc_traffic_dptn_audio.json"),
+              "dprnn_av": os.path.join(ROOT, "profiles", "r05_pmc_traffic_dprnn_av.json")}
 PMC_TABLE = PMC_TABLES["dptn_av"]
-PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r04_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
+PMC_TABLE_TRAIN = os.path.join(ROOT, "profiles", "r05_train_pmc_traffic.json")   # tools/gpu_train_traffic.sh
 
 
 def pmc_table(config: str, path: str = None):

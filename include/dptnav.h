@@ -293,7 +293,13 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "inject_fail" (n > 0): fault injection for the error-path tests -- the n-th GEMM-engine launch from now on returns
  *                 DPTNAV_ERR_INVALID (once); the forked entry points must still join their internal streams.
  *   "lstm_stamps" (0/1): diagnostic LSTM build that writes per-wave s_memtime segment sums (u64 [dir][tile][wave][4]:
- *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap. */
+ *                 accumulator init, MFMA, cell update, barrier) to the "lstm_stamps" workspace tap.
+ *   "attn_v2" (0/1, default 1): the fused attention block of the inference forward (num_features = 128) in the form with both
+ *                 LayerNorms in fragment space and the FFN prologue's rows by LDS-DMA (attn_block2.hip); 0 = round 2-4's kernel
+ *                 (attn_block.hip, kept for same-process A/B).  Same results up to the grouping of the LayerNorm sums (> 100 dB).
+ *   "train_fuse_probe" (0/1, default 0): MEASUREMENT ONLY (tools/train_fuse_probe.py) -- the training forward runs the inference
+ *                 attention block: no qkv / attention / LayerNorm tape is written and no dropout is applied.  While it is set
+ *                 dptnav_train_backward and dptnav_train_path_backward return DPTNAV_ERR_INVALID. */
 int dptnav_set_option(dptnav_handle h, const char* key, int value);
 
 /* Opt-in per-kernel timing: while enabled every launch is bracketed by two hipEvents recorded on the

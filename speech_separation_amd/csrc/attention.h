@@ -33,7 +33,8 @@ template <int DH, int NKB>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_kernel(const float* __restrict__ qkv,
                                                               float* __restrict__ out, int N, int heads, SeqGeom g,
                                                               float scale_log2e, DropCfg drop,
-                                                              float2* __restrict__ stats_out = nullptr) {
+                                                              float2* __restrict__ stats_out = nullptr,
+                                                              unsigned long long* __restrict__ mask_out = nullptr) {
   using Sh = AttnShape<DH>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                        // [NKB*32][LDK]
@@ -135,13 +136,38 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
   // with them the backward handles one key block at a time instead of keeping the whole score row in registers
   if (stats_out != nullptr && hh == 0 && qb * 32 + c < len)
     stats_out[(tok0 + (int64_t)(qb * 32 + c) * tstride) * heads + head] = make_float2(mx, inv);
-  if (drop.thresh != 0u) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
+  if (drop.thresh != 0u || mask_out != nullptr) {   // train-mode dropout on the (normalised) probabilities; the normaliser keeps all keys
     const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)(qb * 32 + c) * tstride) * (uint32_t)heads + (uint32_t)head);
+    // The keep decisions go to the tape as BIT MASKS (training forward): the compare of register (rb, r) is a 64-bit lane mask
+    // already -- bit L = keep(query c(L), key 32 rb + ROW32(r, hh(L))) -- so word (rb, r) of this wave costs two v_writelane to
+    // park (lane 16 rb + r of a register pair) and the wave's 16 NKB words leave as one or two coalesced 8-byte stores per lane.
+    // Both backward kernels then READ the decision (one select on the mask, or a bit extract in the transposed phase) instead
+    // of re-hashing it: the hash was ~850 of their ~1 700 vector instructions beside 160-240 MFMAs.
+    //   mask[seq][head][qb][rb][r] (uint64)
+    int wlo[2] = {0, 0}, whi[2] = {0, 0};
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        s[rb][r] = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh ? s[rb][r] * drop.inv_keep : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        const bool keep = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh;
+        s[rb][r] = keep ? s[rb][r] * drop.inv_keep : 0.f;
+        // (parked unconditionally -- a branch per element otherwise; only the stores below depend on mask_out.  The s_nop is
+        //  REQUIRED: the mask comes out of a v_cmp, and a v_writelane that reads an SGPR in the instruction slot behind the VALU
+        //  instruction that wrote it gets the OLD value -- the compiler's hazard pass does not look inside an asm statement.  Found
+        //  on the hardware: every low half written directly behind its compare was 0, every high half, one slot later, correct.)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int idx = rb * 16 + r;
+        asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+            : "+v"(wlo[idx >> 6]), "+v"(whi[idx >> 6])
+            : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(idx & 63));
+      }
+    if (mask_out != nullptr) {
+      unsigned long long* mw = mask_out + ((((int64_t)seq * heads + head) * NKB + qb) * NKB) * 16;
+      if (lane < (16 * NKB < 64 ? 16 * NKB : 64))
+        mw[lane] = (unsigned long long)(unsigned)wlo[0] | ((unsigned long long)(unsigned)whi[0] << 32);
+      if (16 * NKB > 64 && lane < 16 * NKB - 64)
+        mw[64 + lane] = (unsigned long long)(unsigned)wlo[1] | ((unsigned long long)(unsigned)whi[1] << 32);
+    }
   }
 
   ATTN_STAMP(3);

@@ -206,15 +206,16 @@ __global__ __launch_bounds__(256) void attn_block2_kernel(const float* __restric
   };
 
   float wkf[64], wvf[64];
-  auto fetch_wkv = [&]() {
+  auto fetch_wkv1 = [&](int m) {      // k-chunk m of this head's W_k / W_v fragments
     const float* wk = wp_in + ((1 * 4 + h) * 16 * 64 + lane) * 4;   // packed: [sel][head][m][lane][4]
     const float* wv = wp_in + ((2 * 4 + h) * 16 * 64 + lane) * 4;
+    const float4 a = ldg4(wk + m * 256), b = ldg4(wv + m * 256);
+    wkf[4 * m + 0] = a.x; wkf[4 * m + 1] = a.y; wkf[4 * m + 2] = a.z; wkf[4 * m + 3] = a.w;
+    wvf[4 * m + 0] = b.x; wvf[4 * m + 1] = b.y; wvf[4 * m + 2] = b.z; wvf[4 * m + 3] = b.w;
+  };
+  auto fetch_wkv = [&]() {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const float4 a = ldg4(wk + m * 256), b = ldg4(wv + m * 256);
-      wkf[4 * m + 0] = a.x; wkf[4 * m + 1] = a.y; wkf[4 * m + 2] = a.z; wkf[4 * m + 3] = a.w;
-      wvf[4 * m + 0] = b.x; wvf[4 * m + 1] = b.y; wvf[4 * m + 2] = b.z; wvf[4 * m + 3] = b.w;
-    }
+    for (int m = 0; m < 16; ++m) fetch_wkv1(m);
   };
   if constexpr (PRO) {
     // ---- prologue: x rows = LN2(ReLU(h) W_f^T + b_f + y1_prev) of the previous path, block of 32 tokens at a time ----
@@ -235,32 +236,56 @@ __global__ __launch_bounds__(256) void attn_block2_kernel(const float* __restric
     const uint32_t hs_lds = lds_addr(Hs);
     const char* const hbase = reinterpret_cast<const char*>(pro.hc) + tok0 * 1024;      // wave-uniform: row pointers stay in SGPRs
     const uint32_t rs_h = (uint32_t)tstride * 1024u;                                     // bytes between consecutive positions in hc
-    // block fetch F(rb) = 8 DMA requests (wave w: rows 8 w .. 8 w + 7 of the block -> Hs[rb & 1]) + the 4 residual fragments of
-    // this lane's token (y1_prev[token c][32 h + 8 j + 4 hh ..]): 12 requests per wave, counted by hand
-    f32x4 res[2][4];
-    auto fetch_blk = [&](auto RB, f32x4 (&rr)[4]) {
-      constexpr int rb = decltype(RB)::value;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int row = rb * 32 + 8 * h + i;
-        if (rb == NKB - 1) row = row < len ? row : len - 1;
-        dma_row(hbase + (uint32_t)row * rs_h, lane16, hs_lds + (uint32_t)(((rb & 1) * 32 + 8 * h + i) * LDHC * 4));
-      }
-      const unsigned ro = row_off(rb * 32 + c, rs_y, rb == NKB - 1) + 4u * frag_col;
-      ldg4_uncounted<0>(rr[0], ybase, ro);
-      ldg4_uncounted<32>(rr[1], ybase, ro);
-      ldg4_uncounted<64>(rr[2], ybase, ro);
-      ldg4_uncounted<96>(rr[3], ybase, ro);
+    // Requests of the prologue, all counted by hand: D(b) = 8 DMA requests (wave w: rows 8 w .. 8 w + 7 of block b -> h buffer
+    // hbuf(b)), R(b) = the 4 residual fragments of this lane's token (y1_prev[token c][32 h + 8 j + 4 hh ..]).
+    // Three h buffers from NKB >= 4: the third is the part of the token-row tile that is written last (x rows of the last two
+    // blocks: 33 792 bytes for 33 280), free until block NKB - 2 is normalised -- so D(b) goes out TWO blocks ahead, behind the
+    // barrier that opens block b - 2 (its buffer's last reader, block b - 3, is through by then).  Measured with two buffers and
+    // one barrier per block the request had one block (~9 k cycles) and the wait for it was 2 k cycles per block, as run.
+    constexpr bool TRI = NKB >= 4;
+    auto hbuf_lds = [&](int b) -> uint32_t {      // LDS byte address of the buffer of block b
+      if (TRI) return (b % 3) == 2 ? lds_addr(Xs) + (uint32_t)((NKB - 2) * 32 * LDX * 4) : hs_lds + (uint32_t)((b % 3) * 32 * LDHC * 4);
+      return hs_lds + (uint32_t)((b & 1) * 32 * LDHC * 4);
     };
-    fetch_blk(std::integral_constant<int, 0>{}, res[0]);
-    if constexpr (NKB > 1) fetch_blk(std::integral_constant<int, 1>{}, res[1]);
-    constexpr int F01 = NKB > 1 ? 24 : 12;      // requests behind the W_f loads
-    wait_vm_a16<F01>(wf4);                      // W_f is in; the first two blocks stay in flight
-    wait_vm_a16<F01>(wf4 + 16);
+    auto hbuf = [&](int b) -> const float* { return TRI ? ((b % 3) == 2 ? Xs + (NKB - 2) * 32 * LDX : Hs + (b % 3) * 32 * LDHC) : Hs + (b & 1) * 32 * LDHC; };
+    f32x4 res[2][4];
+    // one request of block rb: k = 0..7 DMA row 8 h + k, k = 8..11 residual fragment k - 8 (k is a constant after unrolling)
+    auto issue_d1 = [&](auto RB, int i) {
+      constexpr int rb = decltype(RB)::value;
+      int row = rb * 32 + 8 * h + i;
+      if (rb == NKB - 1) row = row < len ? row : len - 1;
+      dma_row(hbase + (uint32_t)row * rs_h, lane16, hbuf_lds(rb) + (uint32_t)((8 * h + i) * LDHC * 4));
+    };
+    auto issue_r1 = [&](auto RB, f32x4 (&rr)[4], int j) {
+      constexpr int rb = decltype(RB)::value;
+      const unsigned ro = row_off(rb * 32 + c, rs_y, rb == NKB - 1) + 4u * frag_col;
+      switch (j) {
+        case 0: ldg4_uncounted<0>(rr[0], ybase, ro); break;
+        case 1: ldg4_uncounted<32>(rr[1], ybase, ro); break;
+        case 2: ldg4_uncounted<64>(rr[2], ybase, ro); break;
+        default: ldg4_uncounted<96>(rr[3], ybase, ro); break;
+      }
+    };
+    auto issue_d = [&](auto RB) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) issue_d1(RB, i);
+    };
+    auto issue_r = [&](auto RB, f32x4 (&rr)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_r1(RB, rr, j);
+    };
+    // issue order: W_f | D(0) R(0) | inside block 0: R(1) D(1) [D(2)] | inside block rb >= 1: R(rb + 1), then D(rb + AHEAD)
+    // (AHEAD = 2 with three buffers, else 1; the first fetch of a sequence is 44 requests back to back -- D(1) is not one of them)
+    constexpr int AHEAD = TRI ? 2 : 1;
+    issue_d(std::integral_constant<int, 0>{});
+    issue_r(std::integral_constant<int, 0>{}, res[0]);
+    constexpr int BEHIND_WF = 12;                      // requests behind the W_f loads
+    wait_vm_a16<BEHIND_WF>(wf4);                       // W_f is in; the first two blocks stay in flight
+    wait_vm_a16<BEHIND_WF>(wf4 + 16);
     AB_MARK(0)
     // One barrier per block: B(rb) publishes the block's h rows AND the LayerNorm statistics of block rb - 1, whose merge /
     // normalise / x -> LDS then runs beside the 128 MFMAs of block rb (it reads LDS and has two dependent chains; alone it waits
-    // out every one of them).  F(rb + 1) goes out behind B(rb): every wave has then finished the MFMAs that read its buffer.
+    // out every one of them).
     f32x16 vprev = zero16();
     float mu_prev = 0.f;
     auto normalise_prev = [&](int pb) {        // x rows of block pb from vprev / mu_prev and the exchanged statistics
@@ -281,13 +306,34 @@ __global__ __launch_bounds__(256) void attn_block2_kernel(const float* __restric
     };
     auto pro_block = [&](auto RB) {
       constexpr int rb = decltype(RB)::value;
-      wait_vm<(rb == 0 && NKB > 1) ? 12 : 0>(res[rb & 1]);    // F(rb) is in (behind F(0) only F(1) is on its way)
-      if constexpr (rb == NKB - 1) fetch_wkv();               // (behind the wait: from here on the compiler's own count is exact)
+      // D(rb) and R(rb) are in; behind them only the rows of block rb + 1 may be on their way: with AHEAD = 2, for 0 < rb < NKB - 1
+      // (requested inside block rb - 1, behind R(rb)).  rb = 0: nothing else has been requested yet; last block: nothing is left.
+      constexpr int KEEP = (AHEAD == 2 && rb >= 1 && rb + 1 < NKB) ? 8 : 0;
+      wait_vm<KEEP>(res[rb & 1]);
       __syncthreads();
-      if constexpr (rb >= 1 && rb + 1 < NKB) fetch_blk(std::integral_constant<int, rb + 1>{}, res[(rb + 1) & 1]);
       AB_MARK(1)
+      // The next requests -- R(rb + 1), then D(rb + AHEAD): the order the waits above count on -- go out ONE AT A TIME between the
+      // MFMAs of the first three quarters of the block (behind every second k-chunk): issued back to back, twelve requests cost
+      // 1.5-2.4 k cycles of a wave that has nothing else to issue (measured: profiles/r05_attn_block2_experiments.txt), beside
+      // MFMAs nothing measurable.  The last quarter shares its region with the normalisation of block rb - 1.
+      // block 0 also requests D(1) (between R(1) and D(2)): slots 0..3 R(rb + 1), 4..11 D(1) [rb = 0] or D(rb + AHEAD), 12..19 D(2)
+      // [rb = 0, three buffers].  The LAST block has nothing left to request: its slots carry this head's W_k / W_v fragments
+      // (ordinary loads; behind the wait above the compiler's own count is exact), which arrive behind its MFMAs.
+      constexpr bool HAS_R = rb + 1 < NKB, HAS_D = rb + AHEAD < NKB && rb + AHEAD >= 2, HAS_D1 = rb == 0 && NKB > 1;
+      constexpr int NREQ = rb == NKB - 1 ? 16 : 4 + (HAS_D1 ? 8 : 0) + (HAS_D ? 8 : 0);
+      auto request = [&](int k) {
+        if constexpr (rb == NKB - 1) {
+          fetch_wkv1(k);
+        } else if (k < 4) {
+          if constexpr (HAS_R) issue_r1(std::integral_constant<int, HAS_R ? rb + 1 : 0>{}, res[(rb + 1) & 1], k);
+        } else if (HAS_D1 && k < 12) {
+          if constexpr (HAS_D1) issue_d1(std::integral_constant<int, 1>{}, k - 4);
+        } else {
+          if constexpr (HAS_D) issue_d1(std::integral_constant<int, HAS_D ? rb + AHEAD : 0>{}, k - (HAS_D1 ? 12 : 4));
+        }
+      };
       f32x16 a0 = zero16(), a1 = zero16();
-      const float* ar = &Hs[((rb & 1) * 32 + c) * LDHC + 4 * hh];
+      const float* ar = hbuf(rb) + c * LDHC + 4 * hh;
 #pragma unroll
       for (int m0 = 0; m0 < 32; m0 += 8) {
         float4 af[8];
@@ -299,14 +345,22 @@ __global__ __launch_bounds__(256) void attn_block2_kernel(const float* __restric
           a1 = mfma32(wf4[m0 + m][1], af[m].y, a1);
           a0 = mfma32(wf4[m0 + m][2], af[m].z, a0);
           a1 = mfma32(wf4[m0 + m][3], af[m].w, a1);
+          // one request behind every k-chunk (20 requests: block 0 with three buffers) or every second one, in the first
+          // three quarters of the block
+          constexpr int EVERY = NREQ > 12 ? 1 : 2;
+          if ((m0 + m) % EVERY == EVERY - 1 && (m0 + m) / EVERY < NREQ && (m0 + m) < 24) {
+            __builtin_amdgcn_sched_barrier(0);        // (MFMAs are scheduled across a volatile asm statement otherwise: pin the place)
+            request((m0 + m) / EVERY);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       if constexpr (rb >= 1) {
         normalise_prev(rb - 1);
 #pragma unroll
-        for (int i = 0; i < 128; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x1f6, 1, 0);     // one of: VALU, SALU, VMEM, DS
+        for (int i = 0; i < 32; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA of the last quarter
+          __builtin_amdgcn_sched_group_barrier(0x1f6, 4, 0);     // four of: VALU, SALU, VMEM, DS
         }
       }
       AB_KEEP(a0[15]) AB_KEEP(a1[15])

@@ -706,13 +706,21 @@ struct AttnBwdShape {
 
 // PHASE 0 and PHASE 1 are separate launches (each gets its own register allocation: together they needed 170 VGPRs,
 // two short of three waves per SIMD); the per-query statistics travel through `stats` [token][head][4].
+// v where the lane's bit of the 64-bit lane mask m (a wave-uniform value: SGPR pair) is set, else 0 -- one instruction
+DEV float keep_by_lane_mask(unsigned long long m, float v) {
+  float o;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(m));
+  return o;
+}
+
 template <int DH, int NKB, int PHASE>
 __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                                   const float* __restrict__ att,
                                                                   const float* __restrict__ datt,
                                                                   float* __restrict__ dqkv, float* __restrict__ stats,
                                                                   int heads, int N, SeqGeom g, float scale, DropCfg drop,
-                                                                  const float2* __restrict__ fstats = nullptr) {
+                                                                  const float2* __restrict__ fstats,
+                                                                  const unsigned long long* __restrict__ amask) {
   using Sh = AttnBwdShape<DH>;
   constexpr int LD = Sh::LD, ROWS = NKB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -790,11 +798,11 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     }
     const float delta = dsum + __shfl_xor(dsum, 32);
     const float mx = ms.x, inv = ms.y;
-    // per-query dropout seed: used here and handed to phase B with the statistics
-    const uint32_t qseed = drop_qseed(drop.seed, (uint32_t)(tok0 + (int64_t)p * tstride) * (uint32_t)heads + (uint32_t)head);
     if (hh == 0 && p < len)
-      *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) =
-          make_float4(mx, inv, delta, __uint_as_float(qseed));
+      *reinterpret_cast<float4*>(stats + ((tok0 + (int64_t)p * tstride) * heads + head) * 4) = make_float4(mx, inv, delta, 0.f);
+    // the forward's keep decisions of this query block (attention.h): word (rb, r) is the lane mask of register (rb, r) in exactly
+    // this layout (lane = query, register = key), read through the scalar unit -- the address is wave-uniform
+    const unsigned long long* mw = amask + ((((int64_t)seq * heads + head) * NKB + __builtin_amdgcn_readfirstlane(qb)) * NKB) * 16;
     f32x16 dq = zero16();
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb) {
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
           // (straight-line: padded keys by select; thresh = 0 / inv_keep = 1 without dropout)
           float pr = fast_exp2(sc[r0 + r] - mx) * inv;
           if (rb == NKB - 1) pr = key < len ? pr : 0.f;
-          const float dpv = drop_rand_q(qseed, (uint32_t)key) >= drop.thresh ? dp[r0 + r] * drop.inv_keep : 0.f;
+          const float dpv = keep_by_lane_mask(mw[rb * 16 + r0 + r], dp[r0 + r] * drop.inv_keep);
           dq = mfma32(pr * (dpv - delta), kk[r], dq);
         }
       }
@@ -902,6 +910,16 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         dp2 = mfma32(d4.z, vf[4 * m + 2], dp2);
         dp2 = mfma32(d4.w, vf[4 * m + 3], dp2);
       }
+      // keep decisions of (query block qb, key block kb), transposed use: this lane's key c sits in register
+      // r' = (c & 3) + 4 (c >> 3) of the lanes with hh' = (c >> 2) & 1 there, its query ROW32(r, hh) is lane ROW32(r, hh) + 32 hh'
+      // -> one 8-byte word per lane and block pair, then bit ROW32(r, 0) of the half selected by hh', shifted by 4 hh
+      uint32_t kw;
+      {
+        const uint2 w2 = *reinterpret_cast<const uint2*>(amask + ((((int64_t)seq * heads + head) * NKB + qb) * NKB + kb) * 16 +
+                                                         ((c & 3) + 4 * (c >> 3)));
+        kw = (((c >> 2) & 1) ? w2.y : w2.x) >> (4 * hh);
+      }
+      const uint32_t ikb = __float_as_uint(drop.inv_keep);
       float qq[16], dd[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -912,7 +930,8 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
         // LDS round trips of a tile.  Without dropout thresh = 0 and inv_keep = 1: every element is "kept".
         const float pexp = fast_exp2(s2[r] * sl2e - pm) * pl;
         const float p2 = key_ok ? pexp : 0.f;
-        const float keep = drop_rand_q(__float_as_uint(st4.w), (uint32_t)key) >= drop.thresh ? drop.inv_keep : 0.f;
+        // (bit -> all ones / zero -> inv_keep / 0.0f: v_bfe_i32 + v_and_b32)
+        const float keep = __uint_as_float((uint32_t)(((int)(kw << (31 - ROW32(r, 0)))) >> 31) & ikb);
         s2[r] = p2 * keep;                          // dropped P (feeds dV)
         dp2[r] = p2 * (dp2[r] * keep - pe);         // dS
         const float qv = Qs[qrow_i * LD + (c < DH ? c : 0)], dv_ = Ds[qrow_i * LD + (c < DH ? c : 0)];

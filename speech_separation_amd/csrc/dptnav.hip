@@ -415,7 +415,7 @@ inline int cap_grid(int64_t ntiles, int cap) { return (int)(ntiles < cap ? ntile
 // ---- attention dispatch over the number of 32-key blocks ----------------------------------------
 template <int DH, int NKB>
 int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads,
-                    hipStream_t st, DropCfg drop, float2* stats) {
+                    hipStream_t st, DropCfg drop, float2* stats, unsigned long long* mask) {
   auto kern = attention_kernel<DH, NKB>;
   const size_t lds = AttnShape<DH>::lds_bytes(NKB);
   static PerDeviceOnce ready;   // per instantiation and device
@@ -425,22 +425,22 @@ int launch_attn_nkb(dptnav_ctx* c, const float* qkv, float* att, int N, const Se
   }
   const float scale = 1.4426950408889634f / sqrtf((float)DH);
   ProfScope ps(c, CAT_ATTN, st);
-  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, heads, g, scale, drop, stats);
+  hipLaunchKernelGGL(kern, dim3(g.nseq, heads), dim3(64 * NKB), lds, st, qkv, att, N, heads, g, scale, drop, stats, mask);
   LAUNCH_CHECK(c, "attention");
   return DPTNAV_OK;
 }
 template <int DH>
 int launch_attn(dptnav_ctx* c, const float* qkv, float* att, int N, const SeqGeom& g, int heads, hipStream_t st,
-                DropCfg drop = DropCfg{0u, 0u, 1.0f}, float2* stats = nullptr) {
+                DropCfg drop = DropCfg{0u, 0u, 1.0f}, float2* stats = nullptr, unsigned long long* mask = nullptr) {
   switch ((g.len + 31) / 32) {
-    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop, stats);
-    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop, stats);
+    case 1: return launch_attn_nkb<DH, 1>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 2: return launch_attn_nkb<DH, 2>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 3: return launch_attn_nkb<DH, 3>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 4: return launch_attn_nkb<DH, 4>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 5: return launch_attn_nkb<DH, 5>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 6: return launch_attn_nkb<DH, 6>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 7: return launch_attn_nkb<DH, 7>(c, qkv, att, N, g, heads, st, drop, stats, mask);
+    case 8: return launch_attn_nkb<DH, 8>(c, qkv, att, N, g, heads, st, drop, stats, mask);
   }
   // longer sequences (inter-chunk path of utterances beyond ~7 s): streaming-softmax kernel, inference only
   if (drop.thresh != 0u) return c->fail(DPTNAV_ERR_INVALID, "attention: dropout needs sequence length <= 256 (got %d)", g.len);
@@ -499,6 +499,7 @@ struct PathBufs {
   float *qkv, *att, *y1, *pre, *hc, *gates, *cst;
   bool train;
   float* astats = nullptr;   // training: where the attention forward leaves its softmax statistics
+  float* amask = nullptr;    // training: ... and its dropout keep decisions as bit masks (attention.h)
   // training, option ln_tape: normalised rows and 1/sigma of LayerNorm 1 / LayerNorm 2 for the backward (EpiBiasResLNSave)
   float *zn1 = nullptr, *rs1 = nullptr, *zn2 = nullptr, *rs2 = nullptr;
 };
@@ -656,7 +657,7 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (dptn && !fused)
     if (int rc = launch_attn<DH>(c, qkv, att, N, geom, g.num_heads, st, c->drop_cfg(block, path, pb.train, run.half),
-                                 reinterpret_cast<float2*>(pb.astats)))
+                                 reinterpret_cast<float2*>(pb.astats), reinterpret_cast<unsigned long long*>(pb.amask)))
       return rc;
   // K3: y1 = LN1(att W_o^T + b_o + x)                           (dptn.py:46-47)
   if (dptn && !fused) {
@@ -958,6 +959,7 @@ int run_tail(dptnav_ctx* c, Run& run, const float* x, const float* E, int B, int
 // =================================================================================================
 struct PathTape {  // offsets in floats inside one path's tape
   size_t qkv, att, y1, hc, gates, cst, astats, total;   // astats: softmax (max, 1/sum) per (token, head)
+  size_t amask;   // dropout keep decisions of the attention forward: [seq][head][qb][kb][16] 64-bit lane masks (attention.h)
   size_t zn1, rs1, zn2, rs2;   // option ln_tape: LayerNorm 1 / 2 normalised rows [M][N] and 1/sigma [M]; 0 when off
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
@@ -982,6 +984,11 @@ int make_path_tape(dptnav_ctx* c, int B, int S, PathTape* t) {
   t->gates = take((size_t)2 * nst * 512 * 32);
   t->cst = take((size_t)2 * nst * 128 * 32);
   t->astats = take(dptn ? (size_t)M * g.num_heads * 2 : 0);
+  {   // 2 floats per word; the larger of the two paths' (sequences x blocks^2)
+    const int64_t nk = (K + 31) / 32, ns = (S + 31) / 32;
+    const int64_t words = std::max((int64_t)B * S * nk * nk, (int64_t)B * K * ns * ns) * g.num_heads * 16;
+    t->amask = take(dptn ? (size_t)words * 2 : 0);
+  }
   t->zn1 = t->rs1 = t->zn2 = t->rs2 = 0;
   if (c->opt_ln_tape) {
     t->zn1 = take(dptn ? (size_t)M * N : 64);      // (never 0: "zn1 != 0" is how the callers see that the LayerNorm tape is on)
@@ -1588,10 +1595,11 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "attention bwd lds: %s", hipGetErrorString(e));
       ProfScope ps(c, CAT_ATTN, st);
       const DropCfg drop = c->drop_cfg(block, path, true, br.half);
+      const unsigned long long* amask = reinterpret_cast<const unsigned long long*>(tape + tp.amask);
       hipLaunchKernelGGL(kern0, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale, drop, reinterpret_cast<const float2*>(tape + tp.astats));
+                         geom, scale, drop, reinterpret_cast<const float2*>(tape + tp.astats), amask);
       hipLaunchKernelGGL(kern1, dim3(geom.nseq, g.num_heads), dim3(threads), lds, st, qkv, att, DATT, DQKV, stats, g.num_heads, N,
-                         geom, scale, drop, (const float2*)nullptr);
+                         geom, scale, drop, (const float2*)nullptr, amask);
       return DPTNAV_OK;
     };
     int rc = DPTNAV_OK;
@@ -2289,7 +2297,7 @@ int dptnav_train_path_forward(dptnav_handle h, int block, int path, const float*
   Run run;
   if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
   float* tb = (float*)tape;
-  PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true, tb + tp.astats};
+  PathBufs pb{tb + tp.qkv, tb + tp.att, tb + tp.y1, run.ws + pl.pre, tb + tp.hc, tb + tp.gates, tb + tp.cst, true, tb + tp.astats, tb + tp.amask};
   if (tp.zn1) { pb.zn1 = tb + tp.zn1; pb.rs1 = tb + tp.rs1; pb.zn2 = tb + tp.zn2; pb.rs2 = tb + tp.rs2; }
   return h->cfg.num_features == 128 ? run_path<128>(h, run, block, path, x_in, x_out, B, S, &pb)
                                     : run_path<64>(h, run, block, path, x_in, x_out, B, S, &pb);
@@ -2300,6 +2308,8 @@ int dptnav_train_path_backward(dptnav_handle h, int block, int path, const float
   if (h->gptr.size() != h->names.size()) return h->fail(DPTNAV_ERR_WEIGHTS, "gradients not bound: call dptnav_bind_grads");
   if (block < 0 || block >= h->cfg.num_blocks || (path != 0 && path != 1) || !x_in || !d_out || !d_in || !tape || !bws)
     return h->fail(DPTNAV_ERR_INVALID, "train_path_backward: bad argument");
+  if (h->opt_train_fuse_probe)
+    return h->fail(DPTNAV_ERR_INVALID, "train_path_backward: option train_fuse_probe is set (measurement only: the forward wrote no tape)");
   PathTape tp;
   make_path_tape(h, B, S, &tp);
   BwdPlan bp;
@@ -2430,7 +2440,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
       }
       float* pt = tb[i] + mt.paths + (size_t)p * mt.path_stride;
       PathBufs pb{pt + mt.pt.qkv, pt + mt.pt.att, pt + mt.pt.y1, run[i].ws + sp.pl[i].pre, pt + mt.pt.hc, pt + mt.pt.gates,
-                  pt + mt.pt.cst, true, pt + mt.pt.astats};
+                  pt + mt.pt.cst, true, pt + mt.pt.astats, pt + mt.pt.amask};
       if (mt.pt.zn1) { pb.zn1 = pt + mt.pt.zn1; pb.rs1 = pt + mt.pt.rs1; pb.zn2 = pt + mt.pt.zn2; pb.rs2 = pt + mt.pt.rs2; }
       if (int rc = (h->cfg.num_features == 128 ? run_path<128>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
                                  tb[i] + mt.X0 + (size_t)(p + 1) * mt.x_stride, sp.Bh[i], (int)sp.pl[i].S, &pb) : run_path<64>(h, run[i], p / 2, p % 2, tb[i] + mt.X0 + (size_t)p * mt.x_stride,
@@ -2477,6 +2487,8 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
   if (!tape || tape_bytes < sp.tape_total * sizeof(float) || !ws || ws_bytes < sp.ws_total * sizeof(float) || ((uintptr_t)ws & 255))
     return h->fail(DPTNAV_ERR_WORKSPACE, "tape or workspace too small / misaligned");
   if (!mix || !d_s1 || !d_s2) return h->fail(DPTNAV_ERR_INVALID, "null tensor argument");
+  if (h->opt_train_fuse_probe)
+    return h->fail(DPTNAV_ERR_INVALID, "train_backward: option train_fuse_probe is set (measurement only: the forward wrote no tape)");
   hipStream_t st = (hipStream_t)stream, si[2];
   if (int rc = train_fork(h, sp, st, si)) return rc;
   auto enqueue = [&]() -> int {   // between fork and join: see join_after

@@ -38,6 +38,7 @@ def load():
         lib.gm_alloc.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         lib.gm_mapped_range.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.gm_free.argtypes = [C.c_void_p]
+        lib.gm_chunks.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -108,8 +109,17 @@ class GuardArena:
             g.copy_(t)
         return g
 
+    def chunks(self):
+        """physical handles per allocation, in allocation order (a buffer above 1 GiB is backed by several)"""
+        return [int(self.lib.gm_chunks(h)) for h in self.handles]
+
     def close(self):
+        """Unmap, release and free every allocation; every step's return code is checked (gm_free reports the first that failed)."""
         self._torch.cuda.synchronize(self.dev)
+        errors = []
         for h in self.handles:
-            self.lib.gm_free(h)
+            if self.lib.gm_free(h):
+                errors.append(self.lib.gm_last_error().decode())
         self.handles = []
+        if errors:
+            raise RuntimeError(f"guardmem: {len(errors)} allocation(s) did not come apart cleanly, first: {errors[0]}")

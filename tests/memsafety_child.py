@@ -145,47 +145,69 @@ def main(mode, variant):
             return {k: place(torch.from_numpy(v)) for k, v in host_inputs[B].items() if k in ("mix", "s1_embedding", "s2_embedding")}
         return eng, inputs_of
 
-    # ---- the plain run: zero-filled buffers from the caching allocator
-    say(f"== {mode} {variant}: plain run")
-    eng, inputs_of = make(lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), lambda t: t.to(dev), False)
-    want = run_sequence(eng, cfg, inputs_of, Bbig, T, Tv, Btrain, lambda t: t.to(dev), full)
-    eng.close()
-    del eng, inputs_of
-    torch.cuda.empty_cache()
+    def plain_run():      # zero-filled buffers from the caching allocator
+        say(f"== {mode} {variant}: plain run")
+        eng, inputs_of = make(lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), lambda t: t.to(dev), False)
+        res = run_sequence(eng, cfg, inputs_of, Bbig, T, Tv, Btrain, lambda t: t.to(dev), full)
+        eng.close()
+        del eng, inputs_of
+        torch.cuda.empty_cache()
+        return res
 
-    # ---- the run under test
-    say(f"== {mode} {variant}: run under test")
-    arena = None
-    if mode == "poison":
-        eng, inputs_of = make(lambda n: torch.full((n,), 0xFF, dtype=torch.uint8, device=dev), lambda t: t.to(dev), False)
-        place = lambda t: t.to(dev)   # noqa: E731
+    def run_under_test(m):
+        say(f"== {m} {variant}: run under test")
+        arena = None
+        if m == "poison":
+            eng, inputs_of = make(lambda n: torch.full((n,), 0xFF, dtype=torch.uint8, device=dev), lambda t: t.to(dev), False)
+            place = lambda t: t.to(dev)   # noqa: E731
+        else:
+            from tests.guardmem import GuardArena
+            arena = GuardArena(0, flush="end" if m == "guard_end" else "start", fill=0xFF)
+            place = lambda t: arena.like(t.contiguous())   # noqa: E731
+            eng, inputs_of = make(lambda n: arena.bytes(n, 256), place, True)
+        res = run_sequence(eng, cfg, inputs_of, Bbig, T, Tv, Btrain, place, full)
+        eng.close()
+        del eng, inputs_of, place
+        if arena is not None:
+            ch = arena.chunks()
+            say(f"guard arena: {len(arena.handles)} allocations, {arena.total / 2**20:.1f} MiB, granularity {arena.granularity}, "
+                f"largest backed by {max(ch)} physical handles")
+            arena.close()           # every unmap / release / address-free return code is checked
+        torch.cuda.empty_cache()
+        return res
+
+    if mode == "all":
+        # ONE-OFF: the history that preceded both faults of round 4 -- plain, poison and guard_end in ONE
+        # process, in that order -- against the hardened allocator.  Not part of the suite.
+        want = plain_run()
+        runs = [(m, run_under_test(m)) for m in ("poison", "guard_end")]
     else:
-        from tests.guardmem import GuardArena
-        arena = GuardArena(0, flush="end" if mode == "guard_end" else "start", fill=0xFF)
-        place = lambda t: arena.like(t.contiguous())   # noqa: E731
-        eng, inputs_of = make(lambda n: arena.bytes(n, 256), place, True)
-    got = run_sequence(eng, cfg, inputs_of, Bbig, T, Tv, Btrain, place, full)
-    eng.close()
-    if arena is not None:
-        say(f"guard arena: {len(arena.handles)} allocations, {arena.total / 2**20:.1f} MiB, granularity {arena.granularity}")
+        # the run under test FIRST: a guard arena then reserves its ranges in a process that has not yet handed 43 GB tapes back
+        # to the driver (the per-mode children still ran the plain pass in front of the arena)
+        got = run_under_test(mode)
+        want = plain_run()
+        runs = [(mode, got)]
 
     # ---- compare
-    bad = []
-    for k in want:
-        a, b = want[k], got[k]
-        if not np.all(np.isfinite(b)):
-            bad.append(f"{k}: non-finite values ({int(np.sum(~np.isfinite(b)))} of {b.size})")
-        elif k.startswith("train0.grad."):      # ticket order varies between runs: fp32 summation order only
-            den = float(np.abs(a).max()) or 1.0
-            if float(np.abs(a - b).max()) > 1e-4 * den:
-                bad.append(f"{k}: differs by {float(np.abs(a - b).max()) / den:.2e} of its maximum")
-        elif not np.array_equal(a, b):
-            bad.append(f"{k}: not bit-identical (max |d| {float(np.abs(a - b).max()):.3e}, {int(np.sum(a != b))} of {a.size} elements)")
-    if bad:
-        say("FAILED\n  " + "\n  ".join(bad[:40]))
-        return 1
-    say(f"OK {mode} {variant}: {len(want)} results identical")
-    return 0
+    rc = 0
+    for m, got in runs:
+        bad = []
+        for k in want:
+            a, b = want[k], got[k]
+            if not np.all(np.isfinite(b)):
+                bad.append(f"{k}: non-finite values ({int(np.sum(~np.isfinite(b)))} of {b.size})")
+            elif k.startswith("train0.grad."):      # ticket order varies between runs: fp32 summation order only
+                den = float(np.abs(a).max()) or 1.0
+                if float(np.abs(a - b).max()) > 1e-4 * den:
+                    bad.append(f"{k}: differs by {float(np.abs(a - b).max()) / den:.2e} of its maximum")
+            elif not np.array_equal(a, b):
+                bad.append(f"{k}: not bit-identical (max |d| {float(np.abs(a - b).max()):.3e}, {int(np.sum(a != b))} of {a.size} elements)")
+        if bad:
+            say(f"FAILED {m}\n  " + "\n  ".join(bad[:40]))
+            rc = 1
+        else:
+            say(f"OK {m} {variant}: {len(want)} results identical")
+    return rc
 
 
 if __name__ == "__main__":

@@ -81,10 +81,10 @@ def test_world2_training_step_allreduces_the_flat_gradient_in_place():
         assert err < 1e-6, (rank, err)                  # mean of two fp32 numbers: exact up to one rounding
 
 
-def _run_bench(extra):
+def _run_bench(extra, gpus=2):
     env = dict(os.environ, BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
                         "--batch", "2", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -106,6 +106,21 @@ def test_bench_launches_its_own_ranks(config):
         assert "error" not in tr, tr
         assert tr["n_gpus"] == 2 and tr["parallelism"].startswith("dp2") and tr["value"] > 0 and np.isfinite(tr["last_loss"])
         assert abs(tr["value"] - 2 * 2 / (tr["ms_per_step"] / 1e3)) < 1e-2 * tr["value"]
+
+
+def test_bench_four_rank_rehearsal_reports_every_rank():
+    """More ranks than two on the one card: four processes share cuda:0 and talk over gloo (the GPU box allows at most six
+    processes on its card, so the eight-rank launch itself is only rehearsed on the CPU: tests/test_parallel_gloo.py).  One
+    JSON line, one throughput entry per rank, and the data-parallel training leg with its gradient all-reduce timed."""
+    line = _run_bench(["--config", "dptn_av"], gpus=4)
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and np.isfinite(line["value"]) and line["value"] > 0
+    assert len(line["per_rank_mixtures_per_sec"]) == 4 and all(v > 0 for v in line["per_rank_mixtures_per_sec"])
+    assert abs(line["value"] - 4 * 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-2 * line["value"]
+    tr = line["train_step"]
+    assert "error" not in tr, tr
+    assert tr["n_gpus"] == 4 and tr["parallelism"].startswith("dp4") and tr["value"] > 0 and np.isfinite(tr["last_loss"])
+    assert len(tr["per_rank_ms_per_step"]) == 4
+    assert "gradient_allreduce" in tr and tr["gradient_allreduce"]
 
 
 def _rccl_worker(port, q):

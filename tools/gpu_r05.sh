@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box, round 4: every profile the bench line and DESIGN quote, taken from ONE tree (write .commit first:
-#   git rev-parse --short HEAD > .commit).   usage: tools/gpu_r04.sh <tag> [parts]     parts: any of  bench trace pmc mfma train
-# Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/r04_*.
+# GPU box, round 5: every profile the bench line and DESIGN quote, taken from ONE tree (write .commit first:
+#   git rev-parse --short HEAD > .commit).   usage: tools/gpu_r05.sh <tag> [parts]     parts: any of  bench trace pmc mfma train
+# Outputs under gpurun_out/<tag>_*; copy what is to be judged into profiles/r05_*.
 set -o pipefail
-TAG=${1:-r04}; PARTS=${2:-"bench trace pmc mfma train"}
+TAG=${1:-r05}; PARTS=${2:-"bench trace pmc mfma train"}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 COMMIT="$(cat $R/.commit 2>/dev/null || echo unknown)"
@@ -66,7 +66,7 @@ fi
 if has bench; then
   # the bench line quotes the traffic tables: give it the ones just taken (same tree, same digest)
   for f in pmc_traffic.json pmc_traffic_dptn_audio.json pmc_traffic_dprnn_av.json train_pmc_traffic.json; do
-    [ -f $O/${TAG}_$f ] && cp $O/${TAG}_$f $R/profiles/r04_$f
+    [ -f $O/${TAG}_$f ] && cp $O/${TAG}_$f $R/profiles/r05_$f
   done
 fi
 cd $R

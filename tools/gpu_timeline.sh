@@ -2,7 +2,7 @@
 # GPU box: kernel timelines (rocprofv3 --kernel-trace) of the forward configurations and of the training step, summarised by
 # tools/timeline_summary.py (kernels / recurrence launches in flight over the last step) -> gpurun_out/<tag>_timeline_summaries.txt
 set -o pipefail
-TAG=${1:-r04}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+TAG=${1:-r05}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
 : > $O/${TAG}_timeline_summaries.txt
 for CFG in dptn_av dptn_audio dprnn_av dptn_av_train; do
