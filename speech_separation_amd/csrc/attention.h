@@ -144,29 +144,36 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     // Both backward kernels then READ the decision (one select on the mask, or a bit extract in the transposed phase) instead
     // of re-hashing it: the hash was ~850 of their ~1 700 vector instructions beside 160-240 MFMAs.
     //   mask[seq][head][qb][rb][r] (uint64)
-    int wlo[2] = {0, 0}, whi[2] = {0, 0};
+    // (fence: the hash does not depend on the softmax, and hoisted above it every compare's mask has to survive until its
+    //  probability exists -- the compiler parked 80 of them in a 129th VGPR by v_writelane / v_readlane pairs)
+    __builtin_amdgcn_sched_barrier(0);
+    int wlo = 0, whi = 0;
+    unsigned long long* mw = mask_out == nullptr ? nullptr : mask_out + ((((int64_t)seq * heads + head) * NKB + qb) * NKB) * 16;
 #pragma unroll
-    for (int rb = 0; rb < NKB; ++rb)
+    for (int rb = 0; rb < NKB; ++rb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool keep = drop_rand_q(qseed, (uint32_t)(rb * 32 + ROW32(r, hh))) >= drop.thresh;
         s[rb][r] = keep ? s[rb][r] * drop.inv_keep : 0.f;
+        asm volatile("" : "+v"(s[rb][r]));      // the select HERE: sunk to the P V loop it kept every mask alive (78 SGPR spills)
         // (parked unconditionally -- a branch per element otherwise; only the stores below depend on mask_out.  The s_nop is
         //  REQUIRED: the mask comes out of a v_cmp, and a v_writelane that reads an SGPR in the instruction slot behind the VALU
         //  instruction that wrote it gets the OLD value -- the compiler's hazard pass does not look inside an asm statement.  Found
         //  on the hardware: every low half written directly behind its compare was 0, every high half, one slot later, correct.)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        const int idx = rb * 16 + r;
         asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-            : "+v"(wlo[idx >> 6]), "+v"(whi[idx >> 6])
-            : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(idx & 63));
+            : "+v"(wlo), "+v"(whi)
+            : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"((rb * 16 + r) & 63));
+        // four elements at a time: left alone the scheduler forms all 16 NKB compares first (they do not depend on the softmax)
+        // and keeps their masks alive in SGPRs -- 82 of them spilled, and the kernel went from 124 to 129 VGPRs = from three
+        // workgroups per CU to two (training step 152.3 -> 150.5 mixtures/s, same-box A/B of two builds)
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-    if (mask_out != nullptr) {
-      unsigned long long* mw = mask_out + ((((int64_t)seq * heads + head) * NKB + qb) * NKB) * 16;
-      if (lane < (16 * NKB < 64 ? 16 * NKB : 64))
-        mw[lane] = (unsigned long long)(unsigned)wlo[0] | ((unsigned long long)(unsigned)whi[0] << 32);
-      if (16 * NKB > 64 && lane < 16 * NKB - 64)
-        mw[64 + lane] = (unsigned long long)(unsigned)wlo[1] | ((unsigned long long)(unsigned)whi[1] << 32);
+      // 64 words are a register pair's worth: key blocks 0..3 leave here, the rest (NKB > 4) behind the last block
+      if ((rb & 3) == 3 || rb == NKB - 1) {
+        const int nw = 16 * ((rb & 3) + 1);
+        if (mw != nullptr && lane < nw) mw[64 * (rb >> 2) + lane] = (unsigned long long)(unsigned)wlo | ((unsigned long long)(unsigned)whi << 32);
+      }
     }
   }
 

@@ -55,6 +55,7 @@ struct Run {
   bool packed_whh4 = false;          // ws + pl.whh4 holds the fragment-order W_hh copies of ALL paths for lstm4.hip (made at its first launch of the pass)
   bool packed_wih = false;           // ws + pl.wih holds the fragment-order W_ih copies of ALL paths; otherwise run_path packs its own
   bool fuse128 = false;              // num_features = 128: input projection inside the recurrence for this pass (dptnav_ctx::fuse128_for)
+  int batch_total = 0;               // mixtures of the whole call this run is a sub-batch of (0: a stage entry point, unknown)
   bool packed = false;               // ws + pl.wpack holds the packed weights of ALL paths (dptnav_forward); otherwise
                                      // run_path packs the path it is about to run
   unsigned* take_queue(int n) {
@@ -690,8 +691,13 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   // (profiles/r03_lstm4_sweep.txt): faster for sub-batches of up to 4 mixtures at 4 s (1.1 rounds; B = 8: 18.0 -> 16.3 ms),
   // slower inside the B = 16 forward when its 5-mixture sub-batches (1.38 rounds) take it (30.5 -> 31.1 ms).
   const int nst4 = (geom.nseq + 3) / 4;
+  // Round 5 (tools/small_batch_sweep.py, profiles/r05_small_batch_sweep.txt): while the whole call is at most 10 mixtures -- two
+  // sub-batches of up to 5, which do not fill the chip between them -- launches of up to 1.5 rounds are still faster on 4-sequence
+  // tiles (B = 8: 16.47 -> 15.68 ms, B = 10: 19.64 -> 19.12 ms); from B = 12 on the chip is full and the 16-sequence tiles' lower
+  // CU-time wins (23.07 vs 22.2 ms).
+  const int rounds20 = (run.batch_total > 0 && run.batch_total <= 10) ? 30 : 23;      // launch size limit in twentieths of a round
   const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
-                    (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= 23 * c->num_cus));
+                    (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= rounds20 * c->num_cus));
   // num_features = 64: input projection inside the recurrence (lstm16x.hip) -- no K4 launch, no pre-activation tensor
   const bool usex = (N == 64 ? c->opt_fuse_pre : run.fuse128) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
@@ -2019,6 +2025,7 @@ int dptnav_stage_path(dptnav_handle h, int block, int path, const float* x_in, f
   Run run;
   if (int rc = begin_run(h, &run, (float*)ws, pl, (hipStream_t)stream)) return rc;
   run.fuse128 = h->fuse128_for(B);
+  run.batch_total = B;
   return h->cfg.num_features == 128 ? run_path<128>(h, run, block, path, x_in, x_out, B, S)
                                     : run_path<64>(h, run, block, path, x_in, x_out, B, S);
 }
@@ -2087,6 +2094,7 @@ int dptnav_forward(dptnav_handle h, const float* mix, const float* e1, const flo
     hipStream_t si = forked ? h->streams[i % nstr] : st;   // sub-batches go round robin over the internal streams
     if (int rc = begin_run(h, &run[i], (float*)ws + base[i], pl[i], si)) return rc;
     run[i].fuse128 = h->fuse128_for(B);      // by the forward's whole batch, not the sub-batch
+    run[i].batch_total = B;
     mixi[i] = mix + b0 * T;
     e1i[i] = e1 ? e1 + b0 * Cv * Tv : nullptr;
     e2i[i] = e2 ? e2 + b0 * Cv * Tv : nullptr;

@@ -41,7 +41,7 @@ hipMemAllocationProp prop_for(int dev) {
   return p;
 }
 // unmap / release / free whatever `g` holds; returns the FIRST error, keeps going (nothing is left mapped because a step failed)
-hipError_t teardown(GuardAlloc* g, const char** where) {
+hipError_t teardown(GuardAlloc* g, const char** where, bool free_va = true) {
   hipError_t first = hipSuccess;
   auto note = [&](hipError_t e, const char* w) {
     if (e != hipSuccess && first == hipSuccess) {
@@ -55,7 +55,7 @@ hipError_t teardown(GuardAlloc* g, const char** where) {
     note(hipMemRelease(g->mem[i]), "hipMemRelease");
     p += g->chunk[i];
   }
-  if (g->va) note(hipMemAddressFree(g->va, g->reserved), "hipMemAddressFree");
+  if (g->va && free_va) note(hipMemAddressFree(g->va, g->reserved), "hipMemAddressFree");
   return first;
 }
 }  // namespace
@@ -99,23 +99,45 @@ int gm_alloc(int dev, size_t bytes, size_t align, int flush_end, void** user_ptr
   acc.location.id = dev;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   char* const base = static_cast<char*>(g->va) + gran;
+  // Back the range by handles of `chunk` bytes, give access, and on ANY failure take everything down again (the reservation stays).
+  // access_per_chunk: one hipMemSetAccess per handle; otherwise one over the whole mapped range.
+  auto build = [&](size_t chunk, bool access_per_chunk, const char** step) -> hipError_t {
+    hipError_t err = hipSuccess;
+    for (size_t off = 0; off < g->mapped && err == hipSuccess; off += chunk) {
+      const size_t n = g->mapped - off < chunk ? g->mapped - off : chunk;
+      hipMemGenericAllocationHandle_t m;
+      if ((err = hipMemCreate(&m, n, &p, 0)) != hipSuccess) {
+        *step = "hipMemCreate";
+        break;
+      }
+      g->mem.push_back(m);
+      g->chunk.push_back(n);
+      if ((err = hipMemMap(base + off, n, 0, m, 0)) != hipSuccess) {
+        *step = "hipMemMap";
+        break;
+      }
+      g->n_mapped = g->mem.size();
+      if (access_per_chunk && (err = hipMemSetAccess(base + off, n, &acc, 1)) != hipSuccess) *step = "hipMemSetAccess (per handle)";
+    }
+    if (err == hipSuccess && !access_per_chunk && (err = hipMemSetAccess(base, g->mapped, &acc, 1)) != hipSuccess)
+      *step = "hipMemSetAccess (whole range)";
+    if (err != hipSuccess) {      // handles and mappings down, the address range stays reserved for the next attempt
+      const char* w = "";
+      (void)teardown(g, &w, /*free_va*/ false);
+      g->mem.clear();
+      g->chunk.clear();
+      g->n_mapped = 0;
+      (void)hipGetLastError();
+    }
+    return err;
+  };
+  // What round 5 found on this runtime (ROCm 7.2, first run of the chunked form): hipMemSetAccess on ONE of several handles mapped
+  // into a reservation returns hipErrorInvalidValue.  So: handles of <= 1 GiB with one hipMemSetAccess over the whole range; if the
+  // runtime refuses that too, one handle for the whole buffer as in round 4 (the synchronise-before-reserve, the checked teardown
+  // and the guard-pass-first order of the children still hold).  gm_chunks() says which form an allocation got.
   const char* step = nullptr;
-  for (size_t off = 0; off < g->mapped && e == hipSuccess; off += CHUNK_BYTES) {
-    const size_t n = g->mapped - off < CHUNK_BYTES ? g->mapped - off : CHUNK_BYTES;
-    hipMemGenericAllocationHandle_t m;
-    if ((e = hipMemCreate(&m, n, &p, 0)) != hipSuccess) {
-      step = "hipMemCreate";
-      break;
-    }
-    g->mem.push_back(m);
-    g->chunk.push_back(n);
-    if ((e = hipMemMap(base + off, n, 0, m, 0)) != hipSuccess) {
-      step = "hipMemMap";
-      break;
-    }
-    g->n_mapped = g->mem.size();
-    if ((e = hipMemSetAccess(base + off, n, &acc, 1)) != hipSuccess) step = "hipMemSetAccess";
-  }
+  e = g->mapped <= CHUNK_BYTES ? build(g->mapped, true, &step) : build(CHUNK_BYTES, false, &step);
+  if (e != hipSuccess && g->mapped > CHUNK_BYTES) e = build(g->mapped, true, &step);
   if (e != hipSuccess) {
     const char* w = "";
     (void)teardown(g, &w);
