@@ -806,6 +806,10 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
     f32x16 dq = zero16();
 #pragma unroll
     for (int rb = 0; rb < NKB; ++rb) {
+      // this key block's 16 mask words: requested here (two s_load_dwordx16), they arrive behind the 32 MFMAs below
+      unsigned long long mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[r] = mw[rb * 16 + r];
       f32x16 sc = zero16(), dp = zero16();
       const float* krow = Ks + (rb * 32 + c) * LD + 4 * hh;
       const float* vrow = Vs + (rb * 32 + c) * LD + 4 * hh;
@@ -830,13 +834,19 @@ __global__ __launch_bounds__(64 * NKB, (NKB >= 4 && NKB <= 6) ? 3 : 2) void atte
           const float kval = Ks[(rb * 32 + ROW32(r0 + r, hh)) * LD + (c < DH ? c : 0)];
           kk[r] = c < DH ? kval : 0.f;
         }
+        // ONE wait for the batch (and the mask words), the dQ MFMAs kept behind it: left alone the compiler sinks every K-row read to
+        // the MFMA that uses it and waits for it there -- 64 `s_waitcnt lgkmcnt(0)` per wave, each an exposed LDS round trip in
+        // front of a dependent MFMA (attention.h's forward has had the same fence since round 1).  Round 5: this, not the hash's
+        // instruction count, is what the kernel's time hangs on (halving its vector instructions moved nothing).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int key = rb * 32 + ROW32(r0 + r, hh);
           // (straight-line: padded keys by select; thresh = 0 / inv_keep = 1 without dropout)
           float pr = fast_exp2(sc[r0 + r] - mx) * inv;
           if (rb == NKB - 1) pr = key < len ? pr : 0.f;
-          const float dpv = keep_by_lane_mask(mw[rb * 16 + r0 + r], dp[r0 + r] * drop.inv_keep);
+          const float dpv = keep_by_lane_mask(mk[r0 + r], dp[r0 + r] * drop.inv_keep);
           dq = mfma32(pr * (dpv - delta), kk[r], dq);
         }
       }

@@ -66,8 +66,23 @@ def run_inference(model: Callable[..., Mapping[str, torch.Tensor]], entries: Lis
     sums = [0.0] * len(metrics)
     met_means = []        # per batch: the metrics' device-side means (read once, after the loop: no stall per batch)
     n_items = 0
+    # The launching thread shares the interpreter lock with the loader threads and the writer: at CPython's default switch interval
+    # (5 ms) every one of its hand-overs can cost that long while a loader holds the lock in pure-Python code, and a batch has
+    # ~28 ms in all.  A shorter interval for the duration of the loop (restored below).
+    import contextlib
+    import sys
+
+    @contextlib.contextmanager
+    def short_switch_interval(seconds=2e-4):
+        old = sys.getswitchinterval()
+        sys.setswitchinterval(min(old, seconds))
+        try:
+            yield
+        finally:
+            sys.setswitchinterval(old)
+
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, torch.no_grad():
+    with short_switch_interval(), ThreadPoolExecutor(max_workers=max(1, workers)) as pool, torch.no_grad():
         load = lambda e: load_item(e, target_sr)
         pending = [[pool.submit(load, e) for e in b] for b in mine[:prefetch]]
         for i in range(len(mine)):

@@ -146,10 +146,9 @@ class PinnedBatcher:
         if buf is None or tuple(buf.shape) != shape or buf.dtype != vals[0].dtype:
             buf = torch.empty(shape, dtype=vals[0].dtype, pin_memory=self.device.type == "cuda")
             pinned[key] = buf
-        o = 0
-        for v in vals:                       # the concatenation itself: written straight into pinned memory
-            buf[o:o + v.shape[0]].copy_(v)
-            o += v.shape[0]
+        # the concatenation itself, written straight into pinned memory by ONE operator call (one GIL hand-over per key instead of
+        # one per item: the loop runs beside a dozen loader threads)
+        torch.cat(vals, dim=0, out=buf)
         return buf
 
     def to_device(self, items: Sequence[Mapping[str, object]]) -> Dict[str, object]:
