@@ -699,7 +699,9 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   const bool use4 = use16 && !split && !pb.train && !c->opt_lstm_stamps &&
                     (c->opt_lstm4 == 2 || (c->opt_lstm4 == 1 && 20 * nst4 * w.ndir <= rounds20 * c->num_cus));
   // num_features = 64: input projection inside the recurrence (lstm16x.hip) -- no K4 launch, no pre-activation tensor
-  const bool usex = (N == 64 ? c->opt_fuse_pre : run.fuse128) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
+  // (the 128-feature kernel addresses hc and its input rows with 32-bit byte offsets: both tensors below 4 GiB)
+  const bool fits32 = (uint64_t)(M + (int64_t)geom.S * geom.K) * (uint64_t)(w.ndir * LSTM_H) * 4u < (1ull << 32);
+  const bool usex = (N == 64 ? c->opt_fuse_pre : (run.fuse128 && fits32)) && c->opt_lstm16 && !pb.train && !split && !use4 && !c->opt_lstm_stamps;
   // K4: LSTM pre-activations for every (direction, sequence tile, position), in accumulator-fragment order
   if (!usex) {
     ALoadSeqTile al{lstm_in, N, geom};

@@ -264,6 +264,15 @@ constexpr int X128_XS_FLOATS = 16 * 128;                       // one step's inp
 constexpr size_t X128_LDS_BYTES = sizeof(float) * (X128_WL_FLOATS + L16_HS_FLOATS + 2 * X128_XS_FLOATS);
 static_assert(X128_LDS_BYTES <= 160 * 1024, "LDS budget");
 
+template <class F, int... I>
+static __device__ __forceinline__ void x16_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, class F>
+static __device__ __forceinline__ void x16_static_for(F&& f) {
+  x16_static_for_impl(f, std::make_integer_sequence<int, N_>{});
+}
+
 template <bool RELU>
 __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wih_f,
                                                           const float* __restrict__ wih_b, const float* __restrict__ bih_f,
@@ -333,26 +342,29 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
   const int t0 = d ? g.len - 1 : 0, tdir = d ? -1 : 1;
   const int tstride = seq_token_stride(g);
   const int srow = 4 * w + (lane >> 5), scol = 4 * (lane & 31);
-  char* hp[2];
-  const int64_t hstep = (int64_t)tdir * tstride * ldh * 4;
+  // h rows and input rows are addressed as a wave-uniform base + a 32-bit byte offset per lane (the host checks that both tensors
+  // are below 4 GiB for this kernel): four registers less than 64-bit pointers, which is what keeps the step loop free of scratch
+  unsigned hp[2];
+  const unsigned hstep = (unsigned)(tdir * tstride * ldh * 4);      // (may be "negative": offsets are taken modulo 2^32)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int q = st * 16 + srow + 2 * j;
     const int64_t tokb = q < g.nseq ? seq_token_base(g, q) : dump_row;
-    hp[j] = reinterpret_cast<char*>(hc) + ((tokb + (int64_t)t0 * tstride) * ldh + d * L16_H + scol) * 4;
+    hp[j] = (unsigned)(((tokb + (int64_t)t0 * tstride) * ldh + d * L16_H + scol) * 4);
   }
+  char* const hcb = reinterpret_cast<char*>(hc);
   // input rows: 16 x 512 bytes per step, by LDS-DMA (no registers): wave w issues two 1-KiB requests, request j = 2w + i covers
   // rows 2j and 2j + 1 -- lane L delivers 16 bytes to LDS position 16 L of the request's KiB, so it FETCHES the chunk that
   // belongs there: row 2j + (L >> 5), chunk (L & 31) ^ (row & 15) (the XOR spreads a fragment read's 16 rows over the banks).
   // Padded sequences read the last real one.
-  const char* xp[2];
-  const int64_t xstep = (int64_t)tdir * tstride * ldx * 4;
+  unsigned xp[2];
+  const unsigned xstep = (unsigned)(tdir * tstride * ldx * 4);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = 2 * (2 * w + i) + (lane >> 5);
     const int q = st * 16 + row;
     const int64_t tokb = seq_token_base(g, q < g.nseq ? q : g.nseq - 1);
-    xp[i] = reinterpret_cast<const char*>(x) + ((tokb + (int64_t)t0 * tstride) * ldx + 4 * ((lane & 31) ^ (row & 15))) * 4;
+    xp[i] = (unsigned)(((tokb + (int64_t)t0 * tstride) * ldx + 4 * ((lane & 31) ^ (row & 15))) * 4);
   }
   // Issued as inline assembly ON PURPOSE (fcln.hip has the long version): through __builtin_amdgcn_global_load_lds the compiler knows
   // that memory -> LDS traffic is outstanding and, unable to tell the buffers apart, puts s_waitcnt vmcnt(0) in front of the NEXT LDS
@@ -361,9 +373,9 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
   // this traffic needs is written by hand at the end of the step.
   const uint32_t xs_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)Xs;
   auto dma_x = [&](int s, int buf, int i) {        // x_s -> Xs[buf], this wave's request i
-    const int64_t adv = (int64_t)(s < g.len ? s : g.len - 1) * xstep;
+    const unsigned adv = (unsigned)(s < g.len ? s : g.len - 1) * xstep;
     const uint32_t dst = xs_lds + (uint32_t)((buf * X128_XS_FLOATS + (2 * w + i) * 256) * 4);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(xp[i] + adv) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(xp[i] + adv), "s"(x) : "memory", "m0");
   };
   dma_x(0, 0, 0); dma_x(0, 0, 1);
   dma_x(1, 1, 0); dma_x(1, 1, 1);
@@ -377,46 +389,61 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
   const int xlane = i16 * 128 + 4 * (ks ^ (i16 & 3));
   const int xq = i16 >> 2;
   // acc = b + x W_ih^T: 16 groups of four fragment sets (k-chunk m = group / 2, blocks 4 (group & 1) .. + 3); the sets that live
-  // in LDS are fetched one group ahead into a ping-pong pair of four float4
+  // in LDS are fetched ONE PAIR of sets (8 MFMAs = 256 cycles) ahead, by hand: written as ordinary loads "one group ahead" the
+  // compiler -- with all 256 + 256 registers in use -- sank every one of them to the MFMA that consumes it and waited for it there:
+  // a dozen exposed LDS round trips per step in the generated loop (`ds_read_b128; s_waitcnt lgkmcnt(0); 32 MFMAs`, round 5).  The
+  // reads are volatile asm statements now (they stay where they are written, 16 registers for two pairs) and each pair is waited
+  // for by one hand-written `s_waitcnt lgkmcnt(0)` that carries the pair's registers as operands.
+  const uint32_t wl_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)wl_wave;
   auto input_part = [&](int buf) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[b] = (f32x4v){bsc[b], bsc[b], bsc[b], bsc[b]};
     const float* xrow = Xs + buf * X128_XS_FLOATS + xlane;
-    float4 fb[2][4];
     float4 xa = *reinterpret_cast<const float4*>(xrow + 16 * (0 ^ xq));
+    static_assert(RES >= 33 && RES <= 34 && (RES & 1) == 1, "sets 0..32 resident: the first LDS pair is (32 resident, 33)");
+    // ---- k-chunks 0..3: sets 0..31, all resident
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      float4 xa_next = xa;
-      if (m + 1 < 8) xa_next = *reinterpret_cast<const float4*>(xrow + 16 * (((m + 1) & 3) ^ xq) + 64 * ((m + 1) >> 2));
+    for (int m = 0; m < 4; ++m) {
+      const float4 xa_next = *reinterpret_cast<const float4*>(xrow + 16 * (((m + 1) & 3) ^ xq) + 64 * ((m + 1) >> 2));
       const float av[4] = {xa.x, xa.y, xa.z, xa.w};
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int gi = 2 * m + half;
-        if (gi + 1 < 16) {
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int p = 4 * (gi + 1) + j;
-            if (p >= RES) fb[(gi + 1) & 1][j] = *reinterpret_cast<const float4*>(wl_wave + (p - RES) * 256);
+            const int p = 8 * m + 4 * half + j;
+            acc[p & 7] = mfma16(av[tt], wiv[p][tt], acc[p & 7]);
           }
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int p = 4 * gi + j, b = p & 7;
-            float bv;
-            if (p < RES) {
-              bv = wiv[p % RES][tt];
-            } else {
-              const float4 f = fb[gi & 1][j];
-              bv = tt == 0 ? f.x : (tt == 1 ? f.y : (tt == 2 ? f.z : f.w));
-            }
-            acc[b] = mfma16(av[tt], bv, acc[b]);
-          }
-        }
-      }
       xa = xa_next;
     }
+    // ---- k-chunks 4..7: sets 32..63 in pairs (p0, p0 + 1); set 32 is resident, the other 31 come from LDS
+    f32x4v fa[2][2];
+    auto request = [](auto CH, f32x4v (&dst)[2], uint32_t base) {      // the LDS sets of pair CH
+      constexpr int p0 = 32 + 2 * decltype(CH)::value;
+      if constexpr (p0 >= RES)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(base), "n"((p0 - RES) * 1024));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(base), "n"((p0 + 1 - RES) * 1024));
+    };
+    request(std::integral_constant<int, 0>{}, fa[0], wl_lds);
+    float4 xa_next = xa;
+    x16_static_for<16>([&](auto CH) {
+      constexpr int ch = decltype(CH)::value, p0 = 32 + 2 * ch, m = p0 >> 3;
+      if constexpr ((p0 & 7) == 0 && m + 1 < 8) xa_next = *reinterpret_cast<const float4*>(xrow + 16 * (((m + 1) & 3) ^ xq) + 64 * ((m + 1) >> 2));
+      // this pair's sets have landed (nothing else of this wave is outstanding on the LDS counter that is younger)
+      if constexpr (p0 >= RES) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ch & 1][0]), "+v"(fa[ch & 1][1]) : : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[ch & 1][1]) : : "memory");
+      if constexpr (ch + 1 < 16) request(std::integral_constant<int, ch + 1 < 16 ? ch + 1 : 0>{}, fa[(ch + 1) & 1], wl_lds);
+      __builtin_amdgcn_sched_barrier(0);      // (the pair's MFMAs behind the request: arithmetic is scheduled across an asm statement otherwise)
+      const float av[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const float b0 = p0 < RES ? wiv[p0 < RES ? p0 : 0][tt] : fa[ch & 1][0][tt];
+        acc[p0 & 7] = mfma16(av[tt], b0, acc[p0 & 7]);
+        acc[(p0 + 1) & 7] = mfma16(av[tt], fa[ch & 1][1][tt], acc[(p0 + 1) & 7]);
+      }
+      if constexpr ((p0 & 7) == 6) xa = xa_next;      // last pair of the k-chunk
+    });
   };
   input_part(0);
   __syncthreads();      // step 0 requests x_2 into the buffer of x_0
@@ -431,7 +458,7 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
     float4 a = *reinterpret_cast<const float4*>(arow);
 #pragma unroll
     for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
-    const int64_t adv = step > 0 ? hstep : 0;
+    const unsigned adv = step > 0 ? hstep : 0u;
 
     // h_{t-1} W_hh^T, k-chunk by k-chunk, all eight blocks per chunk; one memory instruction per MFMA group in the first
     // groups: the stores of h_{t-1}, the input rows of step + 2 to LDS, the requests for the rows of step + 3
@@ -448,7 +475,7 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
         if (slot < 2) {
           asm volatile("" : "+v"(hs[slot].x), "+v"(hs[slot].y), "+v"(hs[slot].z), "+v"(hs[slot].w));
           if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
-          *reinterpret_cast<float4*>(hp[slot]) = hs[slot];
+          *reinterpret_cast<float4*>(hcb + hp[slot]) = hs[slot];
           hp[slot] += adv;
           __builtin_amdgcn_sched_barrier(0);
         } else if (slot < 4) {
@@ -482,7 +509,7 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
     for (int j = 0; j < 2; ++j) {
       float4 v = *reinterpret_cast<const float4*>(hfin + (srow + 2 * j) * L16_LDH + scol);
       if (RELU) v = make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w));
-      *reinterpret_cast<float4*>(hp[j]) = v;
+      *reinterpret_cast<float4*>(hcb + hp[j]) = v;
     }
   }
 }
