@@ -430,6 +430,32 @@ def test_training_step_matches_reference_gradients(dev, golden, name, copies, ls
     assert abs(float(norm) - float(z["val.grad_norm"])) < 1e-4 * float(z["val.grad_norm"])
 
 
+def test_backward_refuses_a_tape_written_under_the_measurement_probe(dev):
+    """Option train_fuse_probe (tools/train_fuse_probe.py) makes the training forward run the inference attention block: no
+    qkv / attention / LayerNorm tape, no dropout.  A backward behind it used to return OK with garbage gradients; both
+    backward entry points now refuse while the option is set, and work again once it is cleared."""
+    cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1})
+    eng, _ = make_engine(cfg, dev)
+    eng.bind_grads()
+    t = to_dev(synthetic_inputs(cfg, B=2, T=4000, Tv=50, seed=3), dev)
+    args = (t["mix"], t["s1_embedding"], t["s2_embedding"])
+    d = torch.randn(2, 4000, device=dev)
+    eng.set_option("train_fuse_probe", 1)
+    s1, s2, tape = eng.train_forward(*args)
+    with pytest.raises(RuntimeError, match="train_fuse_probe"):
+        eng.train_backward(*args, d, d, tape)
+    S = eng.chunks(4000)
+    x = torch.randn(2, S, cfg.chunk_size, cfg.num_features, device=dev)
+    y, ptape = eng.train_path_forward(0, 0, x)
+    with pytest.raises(RuntimeError, match="train_fuse_probe"):
+        eng.train_path_backward(0, 0, x, torch.randn_like(x), ptape)
+    eng.set_option("train_fuse_probe", 0)
+    s1, s2, tape = eng.train_forward(*args)
+    eng.train_backward(*args, d, d, tape)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(g).all() for g in eng._grads.values())
+
+
 def test_training_rejects_long_video_before_launching_anything(dev):
     """the training step's limit of 256 video frames is reported by the size queries / dptnav_train_forward,
     not by the last stage of the backward after the whole step has run; inference takes the same clip."""
