@@ -434,10 +434,13 @@ def test_backward_refuses_a_tape_written_under_the_measurement_probe(dev):
     """Option train_fuse_probe (tools/train_fuse_probe.py) makes the training forward run the inference attention block: no
     qkv / attention / LayerNorm tape, no dropout.  A backward behind it used to return OK with garbage gradients; both
     backward entry points now refuse while the option is set, and work again once it is cleared."""
+    from speech_separation_amd.engine import DptnEngine, params_to_device
+    from speech_separation_amd.spec import synthetic_inputs
     cfg = DPTNConfig(**{**DPTN_AV.to_dict(), "num_blocks": 1})
-    eng, _ = make_engine(cfg, dev)
+    eng = DptnEngine(cfg, dev)
+    eng.bind(params_to_device(synthetic_state_dict(cfg, seed=0), dev))
     eng.bind_grads()
-    t = to_dev(synthetic_inputs(cfg, B=2, T=4000, Tv=50, seed=3), dev)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in synthetic_inputs(cfg, B=2, T=4000, Tv=50, seed=3).items()}
     args = (t["mix"], t["s1_embedding"], t["s2_embedding"])
     d = torch.randn(2, 4000, device=dev)
     eng.set_option("train_fuse_probe", 1)
