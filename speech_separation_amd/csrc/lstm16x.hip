@@ -395,15 +395,38 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
   // reads are volatile asm statements now (they stay where they are written, 16 registers for two pairs) and each pair is waited
   // for by one hand-written `s_waitcnt lgkmcnt(0)` that carries the pair's registers as operands.
   const uint32_t wl_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)wl_wave;
+  // k-chunk 0 of the NEXT step's input part is held back: its x fragment is read here (x0) and its 32 MFMAs -- registers only, sets
+  // 0..7 are resident -- are issued by the next step right behind the barrier, in front of the recurrent product, where they cover
+  // the round trip of the first h fragment (which cannot be requested before the barrier).
+  // (HALF of it: k = 0, 1 of every lane's four -- 16 MFMAs = 512 cycles cover an LDS round trip, and two registers across the
+  //  barrier fit where four brought a scratch reload into the loop)
+  f32x2 x0;
+  auto input_chunk0 = [&](float t0v, float t1v, int tt0) {
+    const float av[2] = {t0v, t1v};
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = 4 * half + j;
+          acc[p & 7] = mfma16(av[tt], wiv[p][tt0 + tt], acc[p & 7]);
+        }
+  };
   auto input_part = [&](int buf) {
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[b] = (f32x4v){bsc[b], bsc[b], bsc[b], bsc[b]};
     const float* xrow = Xs + buf * X128_XS_FLOATS + xlane;
-    float4 xa = *reinterpret_cast<const float4*>(xrow + 16 * (0 ^ xq));
+    {
+      const float4 xc0 = *reinterpret_cast<const float4*>(xrow + 16 * (0 ^ xq));
+      x0 = (f32x2){xc0.x, xc0.y};
+      input_chunk0(xc0.z, xc0.w, 2);      // k = 2, 3 of chunk 0 now, k = 0, 1 behind the barrier
+    }
+    float4 xa = *reinterpret_cast<const float4*>(xrow + 16 * (1 ^ xq));
     static_assert(RES >= 33 && RES <= 34 && (RES & 1) == 1, "sets 0..32 resident: the first LDS pair is (32 resident, 33)");
-    // ---- k-chunks 0..3: sets 0..31, all resident
+    // ---- k-chunks 1..3: sets 8..31, all resident
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 1; m < 4; ++m) {
       const float4 xa_next = *reinterpret_cast<const float4*>(xrow + 16 * (((m + 1) & 3) ^ xq) + 64 * ((m + 1) >> 2));
       const float av[4] = {xa.x, xa.y, xa.z, xa.w};
 #pragma unroll
@@ -452,12 +475,13 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
     const float* hcur = Hs + (step & 1) * 16 * L16_LDH;
     float* hnext = Hs + ((step + 1) & 1) * 16 * L16_LDH;
     const float* arow = hcur + i16 * L16_LDH + 4 * ks;
-    float4 hs[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) hs[j] = *reinterpret_cast<const float4*>(hcur + (srow + 2 * j) * L16_LDH + scol);
+    // (the two h rows this lane stores: the second is read when the first has left -- one of them live at a time)
+    float4 hs = *reinterpret_cast<const float4*>(hcur + srow * L16_LDH + scol);
     float4 a = *reinterpret_cast<const float4*>(arow);
 #pragma unroll
     for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(acc[b]));
+    input_chunk0(x0.x, x0.y, 0);      // (this step's x_t, fragment read before the barrier)
+    __builtin_amdgcn_sched_barrier(0);  // (these 16 MFMAs FIRST: the h row store below was scheduled in front of them, with its wait)
     const unsigned adv = step > 0 ? hstep : 0u;
 
     // h_{t-1} W_hh^T, k-chunk by k-chunk, all eight blocks per chunk; one memory instruction per MFMA group in the first
@@ -473,10 +497,11 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
         for (int b = 0; b < 8; ++b) acc[b] = mfma16(av[tt], wf[b][4 * m + tt], acc[b]);
         const int slot = 4 * m + tt;
         if (slot < 2) {
-          asm volatile("" : "+v"(hs[slot].x), "+v"(hs[slot].y), "+v"(hs[slot].z), "+v"(hs[slot].w));
-          if (RELU) hs[slot] = make_float4(relu1(hs[slot].x), relu1(hs[slot].y), relu1(hs[slot].z), relu1(hs[slot].w));
-          *reinterpret_cast<float4*>(hcb + hp[slot]) = hs[slot];
+          asm volatile("" : "+v"(hs.x), "+v"(hs.y), "+v"(hs.z), "+v"(hs.w));
+          if (RELU) hs = make_float4(relu1(hs.x), relu1(hs.y), relu1(hs.z), relu1(hs.w));
+          *reinterpret_cast<float4*>(hcb + hp[slot]) = hs;
           hp[slot] += adv;
+          if (slot == 0) hs = *reinterpret_cast<const float4*>(hcur + (srow + 2) * L16_LDH + scol);
           __builtin_amdgcn_sched_barrier(0);
         } else if (slot < 4) {
           dma_x(step + 2, step & 1, slot - 2);    // x_{step+2} -> the buffer of x_step (last read before the previous barrier)
