@@ -23,6 +23,7 @@ SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "
            # attn_block.hip: the softmax works on MFMA results with plain VALU instructions -> accumulators in architectural VGPRs
            "attn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "attn_block2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "dgrad_t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "attn_block64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm16s.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "lstm4.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

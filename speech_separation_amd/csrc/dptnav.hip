@@ -19,6 +19,7 @@
 #include "lstm.h"
 #include "lstm16.h"
 #include "fcln.h"
+#include "dgrad_t.h"
 #include "sisnr.h"
 #include "train_tail.h"
 #include "backward.h"
@@ -99,6 +100,7 @@ struct dptnav_ctx {
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_dgrad_t = true;          // training: the K = 512 data gradient (d P W_ih) by dgrad_t.hip instead of the GEMM engine
   bool opt_attn_v2 = true;          // ... in the form with both LayerNorms in fragment space and h rows by LDS-DMA (attn_block2.hip)
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
   bool opt_wgrad_ride = true;       // training: out-projection / ffn weight gradients formed inside their data-gradient GEMMs
@@ -585,6 +587,32 @@ static int try_fcln(dptnav_ctx* c, hipStream_t st, const FclnArgs& fa, int cat, 
   if (rc == 0) return 1;
   if (rc == (int)hipErrorInvalidValue) {
     (void)hipGetLastError();
+    return 0;
+  }
+  const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+  return e < 0 ? e : -e;
+}
+
+// dgrad_t.hip for one K = 512 data-gradient launch (out = addend + A W, option dgrad_t).  Returns like try_fcln: 1 launched,
+// 0 not taken (the caller uses the GEMM engine), negative DPTNAV error.
+static int try_dgrad_t(dptnav_ctx* c, Run& run, const char* what, const float* A, int lda, const float* W, const float* addend,
+                       float* out, int64_t M) {
+  if (!c->opt_dgrad_t) return 0;
+  if (int rc = inject_failure(c, what)) return rc < 0 ? rc : -rc;
+  if (run.slot + 1 > QUEUE_SLOTS) {
+    const int e = c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
+    return e < 0 ? e : -e;
+  }
+  DgradTArgs a;
+  a.A = A; a.lda = lda; a.W = W; a.addend = addend; a.out = out; a.M = M; a.kin = 512;
+  unsigned* const queue = run.take_queue(1);
+  a.queue = c->opt_deterministic ? nullptr : queue;
+  ProfScope ps(c, CAT_LSTM_PRE, run.st);
+  const int rc = dgrad_t_launch(run.st, a, c->num_cus);
+  if (rc == 0) return 1;
+  if (rc == (int)hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    run.slot -= 1;
     return 0;
   }
   const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
@@ -1302,6 +1330,9 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
+      const int t = try_dgrad_t(c, run, "d x", DG + d * 512, nd * 512, w.w_ih[d], d == 0 ? d_out : d_in, d_in, M);
+      if (t < 0) return -t;
+      if (t) continue;
       ALoadCols al{DG, M, nd * 512, d * 512, 32};
       EpiAddMaskStoreT<true, false> ep{d_in, d == 0 ? d_out : d_in, nullptr, M, N, 32, N};
       if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d], ntiles, 1, al, ep, nullptr, N)) return rc;
@@ -1519,6 +1550,9 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
+      const int t = try_dgrad_t(c, run, "d y1", DG + d * 512, nd * 512, w.w_ih[d], d == 0 ? DZ : DY1, DY1, M);
+      if (t < 0) return -t;
+      if (t) continue;
       ALoadCols al{DG, M, nd * 512, d * 512, 32};
       EpiAddMaskStoreT<true, false> ep{DY1, d == 0 ? DZ : DY1, nullptr, M, N, 32, N};
       if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d y1", w.w_ih[d], ntiles, 1, al, ep, nullptr, N))
@@ -2627,6 +2661,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   }
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "attn_v2") h->opt_attn_v2 = value != 0;
+  else if (k == "dgrad_t") h->opt_dgrad_t = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "ln_tape") h->opt_ln_tape = value != 0;
