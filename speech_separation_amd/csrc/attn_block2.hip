@@ -40,9 +40,10 @@ DEV float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 // One LDS-DMA request: lane L's 16 bytes at (wave-uniform base + voff) land at LDS byte address lds_base + 16 L.  Inline assembly on
 // purpose (fcln.hip has the long version): issued through the builtin, the compiler waits with vmcnt(0) in front of every later LDS
-// access.  Every wait on this traffic is written by hand below.
+// access.  Every wait on this traffic is written by hand below.  (s_nop: the wait state the ISA asks for between a scalar write of
+// M0 and an LDS-DMA that reads it; the hazard recogniser does not look into inline assembly.)
 DEV void dma_row(const void* sbase, uint32_t voff, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 // a fragment load the compiler does not count (same reason): 16 bytes at base + voff + OFF
 template <int OFF>

@@ -593,10 +593,11 @@ static int try_fcln(dptnav_ctx* c, hipStream_t st, const FclnArgs& fa, int cat, 
   return e < 0 ? e : -e;
 }
 
-// dgrad_t.hip for one K = 512 data-gradient launch (out = addend + A W, option dgrad_t).  Returns like try_fcln: 1 launched,
-// 0 not taken (the caller uses the GEMM engine), negative DPTNAV error.
-static int try_dgrad_t(dptnav_ctx* c, Run& run, const char* what, const float* A, int lda, const float* W, const float* addend,
-                       float* out, int64_t M) {
+// dgrad_t.hip for one wide data-gradient launch (out = addend + A W, kin = 512 or 384; option dgrad_t).  `Wpacked`: the
+// fragment-order copy pack_dgrad_t made on the same stream.  Returns like try_fcln: 1 launched, 0 not taken (the caller uses the
+// GEMM engine), negative DPTNAV error.
+static int try_dgrad_t(dptnav_ctx* c, Run& run, int cat, const char* what, const float* A, int lda, int kin, const float* Wpacked,
+                       const float* addend, float* out, int64_t M) {
   if (!c->opt_dgrad_t) return 0;
   if (int rc = inject_failure(c, what)) return rc < 0 ? rc : -rc;
   if (run.slot + 1 > QUEUE_SLOTS) {
@@ -604,10 +605,10 @@ static int try_dgrad_t(dptnav_ctx* c, Run& run, const char* what, const float* A
     return e < 0 ? e : -e;
   }
   DgradTArgs a;
-  a.A = A; a.lda = lda; a.W = W; a.addend = addend; a.out = out; a.M = M; a.kin = 512;
+  a.A = A; a.lda = lda; a.W = Wpacked; a.addend = addend; a.out = out; a.M = M; a.kin = kin;
   unsigned* const queue = run.take_queue(1);
   a.queue = c->opt_deterministic ? nullptr : queue;
-  ProfScope ps(c, CAT_LSTM_PRE, run.st);
+  ProfScope ps(c, cat, run.st);
   const int rc = dgrad_t_launch(run.st, a, c->num_cus);
   if (rc == 0) return 1;
   if (rc == (int)hipErrorInvalidValue) {
@@ -617,6 +618,13 @@ static int try_dgrad_t(dptnav_ctx* c, Run& run, const char* what, const float* A
   }
   const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
   return e < 0 ? e : -e;
+}
+// ... and the copies it reads: one or two [kin][128] weights -> dst (weights change every step: packed where they are used)
+static int pack_dgrad_t(dptnav_ctx* c, hipStream_t st, const float* w0, const float* w1, int kin, float* dst) {
+  if (!c->opt_dgrad_t) return DPTNAV_OK;
+  const int rc = dgrad_t_pack_launch(st, w0, w1, kin, dst);
+  if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "dgrad_t weight pack: %s", hipGetErrorString((hipError_t)rc));
+  return DPTNAV_OK;
 }
 
 template <int N>
@@ -1000,6 +1008,7 @@ struct PathTape {  // offsets in floats inside one path's tape
 };
 struct BwdPlan {   // offsets in floats inside the backward workspace
   size_t queue, dz, dh, dg, dy1, datt, dqkv, slab, lnp, dxa, dxb, dq, du, de, dvi, dv, total;
+  size_t wiht;                      // fragment-order copies of the weights dgrad_t.hip multiplies by (2 x W_ih, in_proj_weight), per path
   size_t dg2, dg3, slab2, queue2;   // more dP buffers / second slab region / ticket counters: the LSTM weight gradients on a side stream (option wgrad_side)
   int slab_wgs;
 };
@@ -1055,6 +1064,7 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv
   p->dg3 = take((size_t)MD * 2 * 4 * H);
   p->slab2 = take((size_t)BWD_SLAB_WGS * 512 * 128);
   p->queue2 = take(QUEUE_SLOTS);
+  p->wiht = take((size_t)3 * 512 * 128);
   p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
   p->dxa = take((size_t)M * N);                     // gradient ping-pong between paths
   p->dxb = take((size_t)M * N);
@@ -1330,7 +1340,10 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      const int t = try_dgrad_t(c, run, "d x", DG + d * 512, nd * 512, w.w_ih[d], d == 0 ? d_out : d_in, d_in, M);
+      if (d == 0)
+        if (int rc = pack_dgrad_t(c, st, w.w_ih[0], nd == 2 ? w.w_ih[1] : nullptr, 512, br.ws + br.pl.wiht)) return rc;
+      const int t = try_dgrad_t(c, run, CAT_LSTM_PRE, "d x", DG + d * 512, nd * 512, 512, br.ws + br.pl.wiht + (size_t)d * 512 * 128,
+                                d == 0 ? d_out : d_in, d_in, M);
       if (t < 0) return -t;
       if (t) continue;
       ALoadCols al{DG, M, nd * 512, d * 512, 32};
@@ -1550,7 +1563,10 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      const int t = try_dgrad_t(c, run, "d y1", DG + d * 512, nd * 512, w.w_ih[d], d == 0 ? DZ : DY1, DY1, M);
+      if (d == 0)
+        if (int rc = pack_dgrad_t(c, st, w.w_ih[0], nd == 2 ? w.w_ih[1] : nullptr, 512, br.ws + br.pl.wiht)) return rc;
+      const int t = try_dgrad_t(c, run, CAT_LSTM_PRE, "d y1", DG + d * 512, nd * 512, 512, br.ws + br.pl.wiht + (size_t)d * 512 * 128,
+                                d == 0 ? DZ : DY1, DY1, M);
       if (t < 0) return -t;
       if (t) continue;
       ALoadCols al{DG, M, nd * 512, d * 512, 32};
@@ -1674,9 +1690,18 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   }
   run.slot = br.slot;
   {
-    ALoadDense al{DQKV, M, 3 * N, BMn};
-    EpiAddMaskStoreT<true, false> ep{d_in, DZ, nullptr, M, N, BMn, N};
-    if (int rc = launch_gemm<3 * N, 1, WRn, WCn, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles_n, 1, al, ep, nullptr, N)) return rc;
+    int t = 0;
+    if constexpr (N == 128) {      // d x = dz + d qkv W_in (K = 384) by dgrad_t.hip
+      float* wp = br.ws + br.pl.wiht + (size_t)2 * 512 * 128;
+      if (int rc = pack_dgrad_t(c, st, w.in_w, nullptr, 384, wp)) return rc;
+      t = try_dgrad_t(c, run, CAT_QKV, "d x", DQKV, 3 * N, 384, wp, DZ, d_in, M);
+      if (t < 0) return -t;
+    }
+    if (!t) {
+      ALoadDense al{DQKV, M, 3 * N, BMn};
+      EpiAddMaskStoreT<true, false> ep{d_in, DZ, nullptr, M, N, BMn, N};
+      if (int rc = launch_gemm<3 * N, 1, WRn, WCn, true>(c, run, CAT_QKV, "d x", w.in_w, ntiles_n, 1, al, ep, nullptr, N)) return rc;
+    }
   }
   br.slot = run.slot;
   return DPTNAV_OK;

@@ -33,7 +33,7 @@ namespace {
 // s_waitcnt vmcnt(0) in front of EVERY LDS access that follows -- it cannot tell the buffers apart -- and a wave sits out the whole
 // latency of the tiles it has just requested, each iteration.  The price: every wait on this traffic is written by hand below.
 static __device__ __forceinline__ void dma16(const void* g, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(g) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(g) : "memory", "m0");
 }
 static __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
