@@ -297,6 +297,10 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "attn_v2" (0/1, default 1): the fused attention block of the inference forward (num_features = 128) in the form with both
  *                 LayerNorms in fragment space and the FFN prologue's rows by LDS-DMA (attn_block2.hip); 0 = round 2-4's kernel
  *                 (attn_block.hip, kept for same-process A/B).  Same results up to the grouping of the LayerNorm sums (> 100 dB).
+ *   "dgrad_t" (0/1, default 1): training backward, num_features = 128 -- the K = 512 data gradient of the LSTM's input product
+ *                 (d y1 = dz + dG W_ih, dptn.py:48) and the K = 384 one of the attention in-projection (dptn.py:46) by dgrad_t.hip
+ *                 (transposed product, rows by LDS-DMA) instead of the GEMM engine; 0 = the engine (kept for same-process A/B).
+ *                 Same sums in another association: gradients agree to fp32 rounding, the forward is untouched.
  *   "train_fuse_probe" (0/1, default 0): MEASUREMENT ONLY (tools/train_fuse_probe.py) -- the training forward runs the inference
  *                 attention block: no qkv / attention / LayerNorm tape is written and no dropout is applied.  While it is set
  *                 dptnav_train_backward and dptnav_train_path_backward return DPTNAV_ERR_INVALID. */
