@@ -43,17 +43,17 @@ DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attr
 // access.  Every wait on this traffic is written by hand below.  (s_nop: the wait state the ISA asks for between a scalar write of
 // M0 and an LDS-DMA that reads it; the hazard recogniser does not look into inline assembly.)
 DEV void dma_row(const void* sbase, uint32_t voff, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 // a fragment load the compiler does not count (same reason): 16 bytes at base + voff + OFF
 template <int OFF>
 DEV void ldg4_uncounted(f32x4& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 // ... into the AGPR half of the register file (the W_f fragments: A operands of the prologue's MFMAs, which read them there)
 template <int OFF>
 DEV void ldg4_uncounted_a(f32x4& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 // wait until at most KEEP of this wave's vector-memory requests are outstanding; sixteen AGPR quads are operands so that no use of
 // them can be scheduled in front of the wait (an asm statement takes at most 30 operands: call it once per half of W_f)

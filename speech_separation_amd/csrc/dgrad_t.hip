@@ -41,10 +41,10 @@ DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attr
 template <bool HALF>
 DEV void dma_part(const void* sbase, uint32_t voff, uint32_t lds_base) {
   if constexpr (!HALF) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_base), "v"(voff), "s"(sbase) : "memory", "m0");
   } else {
     uint32_t saved;
-    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, exec_hi\n\ts_mov_b32 exec_hi, 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 exec_hi, %0"
+    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b32 %0, exec_hi\n\ts_mov_b32 exec_hi, 0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 exec_hi, %0"
                  : "=&s"(saved)
                  : "s"(lds_base), "v"(voff), "s"(sbase)
                  : "memory", "m0");
@@ -53,18 +53,18 @@ DEV void dma_part(const void* sbase, uint32_t voff, uint32_t lds_base) {
 // fragment load / store the compiler does not count: 16 bytes at base + voff + OFF
 template <int OFF>
 DEV void ldg4_uncounted(f32x4& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 // ... into the AGPR half of the register file
 template <int OFF>
 DEV void ldg4_uncounted_a(f32x4& dst, const void* sbase, uint32_t voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int OFF>
 DEV void stg4_uncounted(void* sbase, uint32_t voff, f32x4 v) {
   // (s_nop: a store of more than 8 bytes reads its data registers for a few cycles after issue, and the hazard recogniser does
   //  not look into inline assembly -- without it the next VALU write to `v` changed what lanes 8-15 / 24-31 of each half stored)
-  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(OFF) : "memory");
 }
 // wait until at most KEEP of this wave's vector-memory operations are outstanding; the registers are operands so that no use of
 // them is scheduled in front of the wait
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void dgrad_t_kernel(const float* __restrict__ 
     if (dyn && tid == 0) {
       // uncounted like the rest (a counted atomic would make the compiler wait for everything, stores included, where the
       // ticket is published); the wait at the end of the tile covers it
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(ticket_ahead) : "v"(0u), "v"(1u), "s"(queue) : "memory");
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(ticket_ahead) : "v"(0u), "v"(1u), "s"(queue) : "memory");
     }
     if (next < ntiles) {
       if (first) body(std::true_type{}, std::false_type{}, next);

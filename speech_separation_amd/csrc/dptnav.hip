@@ -20,6 +20,7 @@
 #include "lstm16.h"
 #include "fcln.h"
 #include "dgrad_t.h"
+#include "dgrad_r.h"
 #include "sisnr.h"
 #include "train_tail.h"
 #include "backward.h"
@@ -100,6 +101,7 @@ struct dptnav_ctx {
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_dgrad_r = true;          // training: the K = 128 data gradients with weight-gradient riders by dgrad_r.hip instead of the GEMM engine
   bool opt_dgrad_t = true;          // training: the K = 512 data gradient (d P W_ih) by dgrad_t.hip instead of the GEMM engine
   bool opt_attn_v2 = true;          // ... in the form with both LayerNorms in fragment space and h rows by LDS-DMA (attn_block2.hip)
   bool opt_fold_tail = true;        // inference: post-processing conv + skip + decoder taps as one folded contraction
@@ -627,6 +629,36 @@ static int pack_dgrad_t(dptnav_ctx* c, hipStream_t st, const float* w0, const fl
   return DPTNAV_OK;
 }
 
+// dgrad_r.hip for one K = 128 data gradient with its weight / bias gradient riding (option dgrad_r): packs W on the stream, launches,
+// leaves the partial tiles in `slab` / `colslab` and their number in *grid.  Returns like try_fcln.
+static int try_dgrad_r(dptnav_ctx* c, Run& run, int cat, const char* what, const float* A, const float* W, int nout, bool gate,
+                       const float* X, float* out, int64_t M, float* wpacked, float* slab, float* colslab, int max_slabs, int* grid) {
+  if (!c->opt_dgrad_r) return 0;
+  if (int rc = inject_failure(c, what)) return rc < 0 ? rc : -rc;
+  if (run.slot + 1 > QUEUE_SLOTS) {
+    const int e = c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
+    return e < 0 ? e : -e;
+  }
+  int rc = dgrad_r_pack_launch(run.st, W, nout, wpacked);
+  if (rc == 0) {
+    DgradRArgs a;
+    a.A = A; a.Wpacked = wpacked; a.X = X; a.out = out; a.M = M; a.nout = nout; a.relu_gate = gate;
+    a.slab = slab; a.colslab = colslab; a.max_slabs = max_slabs;
+    unsigned* const queue = run.take_queue(1);
+    a.queue = c->opt_deterministic ? nullptr : queue;
+    ProfScope ps(c, cat, run.st);
+    rc = dgrad_r_launch(run.st, a, c->num_cus, grid);
+    if (rc == 0) return 1;
+    run.slot -= 1;
+  }
+  if (rc == (int)hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+  return e < 0 ? e : -e;
+}
+
 template <int N>
 int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, float* x_out, int B, int S,
              const PathBufs* bufs = nullptr, int chain = 0) {
@@ -1064,7 +1096,7 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv
   p->dg3 = take((size_t)MD * 2 * 4 * H);
   p->slab2 = take((size_t)BWD_SLAB_WGS * 512 * 128);
   p->queue2 = take(QUEUE_SLOTS);
-  p->wiht = take((size_t)3 * 512 * 128);
+  p->wiht = take((size_t)4 * 512 * 128);      // + the rider launches' weight (dgrad_r.hip)
   p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
   p->dxa = take((size_t)M * N);                     // gradient ping-pong between paths
   p->dxb = take((size_t)M * N);
@@ -1449,12 +1481,17 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
         float* slab = br.ws + br.pl.slab;
         int rgrid = 0;
+        const int t = try_dgrad_r(c, run, CAT_FFN, "d h + d ffn weight", DZ, w.ffn_w, 2 * LSTM_H, true, hc, DHb, M,
+                                  br.ws + br.pl.wiht + (size_t)3 * 512 * 128, slab, slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, BWD_SLAB_WGS,
+                                  &rgrid);
+        if (t < 0) return -t;
         // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
         WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
                                                        slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, M};
-        if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
-                                                          2 * LSTM_H, &rgrid, rd))
-          return rc;
+        if (!t)
+          if (int rc = launch_gemm<N, 2, 1, 4, true, false>(c, run, CAT_FFN, "d h + d ffn weight", w.ffn_w, ntiles, 1, al, ep, nullptr,
+                                                            2 * LSTM_H, &rgrid, rd))
+            return rc;
         br.slot = run.slot;
         if (int rc = reduce_rider<N, 2 * LSTM_H>(c, br, "d ffn weight + bias", rgrid, BWD_SLAB_WGS, G("ffn.1.weight"), G("ffn.1.bias")))
           return rc;
@@ -1610,10 +1647,14 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
       float* slab = br.ws + br.pl.slab;
       int rgrid = 0;
+      const int t = try_dgrad_r(c, run, CAT_OUTPROJ, "d att + d out weight", DZ, w.out_w, N, false, att, DATT, M,
+                                br.ws + br.pl.wiht + (size_t)3 * 512 * 128, slab, slab + (size_t)BWD_SLAB_WGS * N * N, BWD_SLAB_WGS, &rgrid);
+      if (t < 0) return -t;
       WgradRider<N, ALoadDense, true> rd{ALoadDense{att, M, N, 32}, slab, slab + (size_t)BWD_SLAB_WGS * N * N, M};
-      if (int rc = launch_gemm<N, 1, 1, 4, true, false>(c, run, CAT_OUTPROJ, "d att + d out weight", w.out_w, ntiles, 1, al, ep,
-                                                        nullptr, N, &rgrid, rd))
-        return rc;
+      if (!t)
+        if (int rc = launch_gemm<N, 1, 1, 4, true, false>(c, run, CAT_OUTPROJ, "d att + d out weight", w.out_w, ntiles, 1, al, ep,
+                                                          nullptr, N, &rgrid, rd))
+          return rc;
       br.slot = run.slot;
       if (int rc = reduce_rider<N, N>(c, br, "d out weight + bias", rgrid, BWD_SLAB_WGS, G("mha.out_proj.weight"), G("mha.out_proj.bias")))
         return rc;
@@ -2687,6 +2728,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "fuse_attn") h->opt_fuse_attn = value != 0;
   else if (k == "attn_v2") h->opt_attn_v2 = value != 0;
   else if (k == "dgrad_t") h->opt_dgrad_t = value != 0;
+  else if (k == "dgrad_r") h->opt_dgrad_r = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "ln_tape") h->opt_ln_tape = value != 0;

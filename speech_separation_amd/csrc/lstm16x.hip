@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void lstm16x128_kernel(const float* __restrict
   auto dma_x = [&](int s, int buf, int i) {        // x_s -> Xs[buf], this wave's request i
     const unsigned adv = (unsigned)(s < g.len ? s : g.len - 1) * xstep;
     const uint32_t dst = xs_lds + (uint32_t)((buf * X128_XS_FLOATS + (2 * w + i) * 256) * 4);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(xp[i] + adv), "s"(x) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(xp[i] + adv), "s"(x) : "memory", "m0");
   };
   dma_x(0, 0, 0); dma_x(0, 0, 1);
   dma_x(1, 1, 0); dma_x(1, 1, 1);
