@@ -562,12 +562,14 @@ def latency_leg(dev, calls: int = 10):
     return res
 
 
-def e2e_inference_leg(dev, forward_mixtures_per_s: float, items: int = 1024, batch: int = 16, T: int = 32000):
+def e2e_inference_leg(dev, forward_mixtures_per_s: float, items: int = 2048, batch: int = 16, T: int = 32000):
     """The reference's Inferencer loop end to end (src/trainer/inferencer.py:98-167 over src/datasets/base_dataset.py:56-135,
     188-205): a synthetic dataset in the reference's formats on local disk (per item three PCM16 WAVs of 4 s at 8 kHz and two
     zlib-compressed .npz lip embeddings), `evaluate.run_inference` = loader threads -> pinned batches + async H2D -> DPTN-AV forward
     -> SI-SNRi on the device -> (optionally) async D2H + one .pth per item.  Items/s with and without the prediction writer, the
-    ratio to the bare forward of THIS run, and each host stage alone so that the one that caps the loop is named."""
+    ratio to the bare forward of THIS run, and each host stage alone so that the one that caps the loop is named.  2 048 items (128
+    batches): the loop's fixed cost -- first batch loaded, last batch's metric and files, 0.08-0.09 s -- is reported on its own
+    (`fill_drain_and_host_s`); at 1 024 items it was 4.5 % of the run, an evaluation set of the reference's size has thousands."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
