@@ -236,7 +236,9 @@ __global__ __launch_bounds__(256) void dgrad_r_kernel(const float* __restrict__ 
     static_for<16>([&](auto S2) {
       constexpr int s2 = decltype(S2)::value, p = s2 & 1;
       if constexpr (s2 + 1 < 16) fetch(s2 + 1, p ^ 1);
-      const float a = (2 * s2 + hh <= last) ? ra[p] : 0.f;      // tokens beyond M (last tile) stay out of dW and db
+      // tokens beyond M stay out of dW and db: only a workgroup's LAST tile can be the batch's last (tile indices grow), so the tiles
+      // with a successor skip the select
+      const float a = (HN || 2 * s2 + hh <= last) ? ra[p] : 0.f;
       csum += a;
 #pragma unroll
       for (int j = 0; j < CB; ++j) {
