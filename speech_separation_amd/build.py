@@ -24,6 +24,7 @@ SOURCES = {"dptnav.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"], "
            "attn_block.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "attn_block2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            "dgrad_t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+           "gemm_t.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
            # dgrad_r.hip: 160 accumulator registers (data gradient + the riding weight gradient) -> AGPR form, weights in VGPRs
            "dgrad_r.hip": [],
            "attn_block64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

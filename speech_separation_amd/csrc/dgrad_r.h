@@ -26,4 +26,6 @@ struct DgradRArgs {
   int max_slabs = 0;
 };
 int dgrad_r_launch(void* stream, const DgradRArgs& a, int num_cus, int* grid_used);
-int dgrad_r_pack_launch(void* stream, const float* W, int nout, float* dst);
+// fragment-order copies of n (<= DGRAD_R_PACK_MAX) row-major [128][nout] weights in ONE launch: srcs[i] (null: skipped) -> dst + dst_off[i]
+constexpr int DGRAD_R_PACK_MAX = 24;
+int dgrad_r_pack_launch(void* stream, const float* const* srcs, const long long* dst_off, int n, int nout, float* dst);

@@ -314,13 +314,21 @@ __global__ __launch_bounds__(256) void dgrad_r_kernel(const float* __restrict__ 
   if (hh == 0) *cs_lane = cs;
 }
 
-// W [128][NOUT] row-major -> [wave 4][nt][k-chunk 16][lane 64][4]
-__global__ __launch_bounds__(256) void dgrad_r_pack_kernel(const float* __restrict__ W, float* __restrict__ dst, int nout) {
-  const int nt_n = nout / 128, n4 = 4 * nt_n * CH * 64;
+// W [128][nout] row-major -> [wave 4][nt][k-chunk 16][lane 64][4]; blockIdx.y = which matrix (null sources are skipped)
+struct DgradRPackArgs {
+  const float* src[DGRAD_R_PACK_MAX];
+  long long dst_off[DGRAD_R_PACK_MAX];      // floats, relative to dst
+  int nout;
+};
+__global__ __launch_bounds__(256) void dgrad_r_pack_kernel(DgradRPackArgs a, float* __restrict__ dst) {
+  const float* W = a.src[blockIdx.y];
+  if (W == nullptr) return;
+  const int nout = a.nout, nt_n = nout / 128, n4 = 4 * nt_n * CH * 64;
+  float4* out = reinterpret_cast<float4*>(dst + a.dst_off[blockIdx.y]);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
     const int lane = i & 63, m = (i >> 6) % CH, nt = ((i >> 6) / CH) % nt_n, w = (i >> 6) / (CH * nt_n);
     const float* wp = W + (size_t)(8 * m + 4 * (lane >> 5)) * nout + (nout / 4) * w + 32 * nt + (lane & 31);
-    reinterpret_cast<float4*>(dst)[i] = make_float4(wp[0], wp[nout], wp[2 * nout], wp[3 * nout]);
+    out[i] = make_float4(wp[0], wp[nout], wp[2 * nout], wp[3 * nout]);
   }
 }
 
@@ -355,8 +363,14 @@ int dgrad_r_launch(void* stream, const DgradRArgs& a, int num_cus, int* grid_use
   return a.nout == 128 ? launch_k<128, false>(stream, a, num_cus, grid_used) : launch_k<256, true>(stream, a, num_cus, grid_used);
 }
 
-int dgrad_r_pack_launch(void* stream, const float* W, int nout, float* dst) {
-  if ((nout != 128 && nout != 256) || !W || !dst) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(dgrad_r_pack_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), W, dst, nout);
+int dgrad_r_pack_launch(void* stream, const float* const* srcs, const long long* dst_off, int n, int nout, float* dst) {
+  if ((nout != 128 && nout != 256) || n < 1 || n > DGRAD_R_PACK_MAX || !srcs || !dst_off || !dst) return (int)hipErrorInvalidValue;
+  DgradRPackArgs pa;
+  for (int i = 0; i < DGRAD_R_PACK_MAX; ++i) {
+    pa.src[i] = i < n ? srcs[i] : nullptr;
+    pa.dst_off[i] = i < n ? dst_off[i] : 0;
+  }
+  pa.nout = nout;
+  hipLaunchKernelGGL(dgrad_r_pack_kernel, dim3(16, n), dim3(256), 0, static_cast<hipStream_t>(stream), pa, dst);
   return (int)hipGetLastError();
 }

@@ -24,5 +24,7 @@ struct DgradTArgs {
   unsigned* queue = nullptr;
 };
 int dgrad_t_launch(void* stream, const DgradTArgs& a, int num_cus);
-// fragment-order copies of one or two (w1 may be null) row-major [kin][128] weights -> dst[0 .. kin*128) and dst[kin*128 ..)
-int dgrad_t_pack_launch(void* stream, const float* w0, const float* w1, int kin, float* dst);
+// fragment-order copies of n (<= DGRAD_PACK_MAX) row-major [kin][128] weights in ONE launch: srcs[i] (null: skipped) -> dst + dst_off[i]
+// (kin x 128 floats each)
+constexpr int DGRAD_PACK_MAX = 24;
+int dgrad_t_pack_launch(void* stream, const float* const* srcs, const long long* dst_off, int n, int kin, float* dst);

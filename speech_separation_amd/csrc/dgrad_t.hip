@@ -315,15 +315,17 @@ __global__ __launch_bounds__(256) void dgrad_t_kernel(const float* __restrict__ 
 }
 
 // [KIN][128] row-major -> the kernel's fragment order [wave 4][k-chunk KIN / 8][lane 64][4]; blockIdx.y = which matrix
+// (null sources -- a path without a reverse direction -- are skipped)
 struct DgradTPackArgs {
-  const float* src[2];
+  const float* src[DGRAD_PACK_MAX];
+  long long dst_off[DGRAD_PACK_MAX];      // floats, relative to dst
   int kin;
 };
 __global__ __launch_bounds__(256) void dgrad_t_pack_kernel(DgradTPackArgs a, float* __restrict__ dst) {
   const float* W = a.src[blockIdx.y];
   if (W == nullptr) return;
   const int ch_n = a.kin / 8, n4 = 4 * ch_n * 64;
-  float4* out = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * a.kin * NOUT);
+  float4* out = reinterpret_cast<float4*>(dst + a.dst_off[blockIdx.y]);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
     const int lane = i & 63, m = (i >> 6) % ch_n, w = (i >> 6) / ch_n;
     const float* wp = W + (size_t)(8 * m + 4 * (lane >> 5)) * NOUT + 32 * w + (lane & 31);
@@ -370,9 +372,14 @@ int dgrad_t_launch(void* stream, const DgradTArgs& a, int num_cus) {
   return a.kin == 512 ? dgrad_t_launch_k<512>(stream, a, num_cus) : dgrad_t_launch_k<384>(stream, a, num_cus);
 }
 
-int dgrad_t_pack_launch(void* stream, const float* w0, const float* w1, int kin, float* dst) {
-  if ((kin != 512 && kin != 384) || !w0 || !dst) return (int)hipErrorInvalidValue;
-  DgradTPackArgs pa{{w0, w1}, kin};
-  hipLaunchKernelGGL(dgrad_t_pack_kernel, dim3(16, w1 ? 2 : 1), dim3(256), 0, static_cast<hipStream_t>(stream), pa, dst);
+int dgrad_t_pack_launch(void* stream, const float* const* srcs, const long long* dst_off, int n, int kin, float* dst) {
+  if ((kin != 512 && kin != 384) || n < 1 || n > DGRAD_PACK_MAX || !srcs || !dst_off || !dst) return (int)hipErrorInvalidValue;
+  DgradTPackArgs pa;
+  for (int i = 0; i < DGRAD_PACK_MAX; ++i) {
+    pa.src[i] = i < n ? srcs[i] : nullptr;
+    pa.dst_off[i] = i < n ? dst_off[i] : 0;
+  }
+  pa.kin = kin;
+  hipLaunchKernelGGL(dgrad_t_pack_kernel, dim3(16, n), dim3(256), 0, static_cast<hipStream_t>(stream), pa, dst);
   return (int)hipGetLastError();
 }

@@ -21,6 +21,7 @@
 #include "fcln.h"
 #include "dgrad_t.h"
 #include "dgrad_r.h"
+#include "gemm_t.h"
 #include "sisnr.h"
 #include "train_tail.h"
 #include "backward.h"
@@ -41,7 +42,7 @@ constexpr int QUEUE_SLOTS = 1024;
 
 struct Plan {  // workspace offsets in floats
   int64_t L, S, M;
-  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, wih, whh4, total;
+  size_t queue, vid, E, X0, X1, qkv, att, y1, pre, hc, stamps, wfold, wpack, wih, whh4, winp, total;
   size_t qkv_n, att_n, y1_n, hc_n;
 };
 
@@ -55,6 +56,7 @@ struct Run {
   hipEvent_t lstm_record = nullptr;  // if set: recorded right after the recurrence launch
   int half = 0;                      // which half of a split batch this run is (salts the dropout seed)
   bool packed_whh4 = false;          // ws + pl.whh4 holds the fragment-order W_hh copies of ALL paths for lstm4.hip (made at its first launch of the pass)
+  bool packed_inw = false;           // ws + pl.winp holds the fragment-order in-projection weights of ALL paths (dptnav_train_forward); otherwise slot 0 = this path
   bool packed_wih = false;           // ws + pl.wih holds the fragment-order W_ih copies of ALL paths; otherwise run_path packs its own
   bool fuse128 = false;              // num_features = 128: input projection inside the recurrence for this pass (dptnav_ctx::fuse128_for)
   int batch_total = 0;               // mixtures of the whole call this run is a sub-batch of (0: a stage entry point, unknown)
@@ -101,6 +103,7 @@ struct dptnav_ctx {
   int opt_lstm4 = 1;          // 4-sequence recurrence tiles (lstm4.hip): 0 never, 1 for launches of up to 1.15 rounds of the chip, 2 whenever PRE16 is in use
   bool opt_split_bf16 = false;      // opt-in: LSTM recurrence on bf16 MFMAs with hi/lo-split operands (lstm16s.hip)
   bool opt_fuse_attn = true;        // inference: K1 + K2 + K3 as one kernel (attn_block.hip) where it applies
+  bool opt_gemm_t = true;           // training forward: the attention in-projection (128 -> 384) by gemm_t.hip instead of the GEMM engine
   bool opt_dgrad_r = true;          // training: the K = 128 data gradients with weight-gradient riders by dgrad_r.hip instead of the GEMM engine
   bool opt_dgrad_t = true;          // training: the K = 512 data gradient (d P W_ih) by dgrad_t.hip instead of the GEMM engine
   bool opt_attn_v2 = true;          // ... in the form with both LayerNorms in fragment space and h rows by LDS-DMA (attn_block2.hip)
@@ -394,6 +397,8 @@ int make_plan(dptnav_ctx* c, int B, int64_t T, int Tv, Plan* p) {
   p->wih = take((size_t)2 * g.num_blocks * 2 * 4 * H * N);
   // ... and of W_hh in the order of the low-latency recurrence (lstm4.hip, `packed`)
   p->whh4 = take((size_t)2 * g.num_blocks * 2 * 4 * H * H);
+  // ... and of the attention in-projection weights of every path, for gemm_t.hip (training forward)
+  p->winp = take(g.arch == 0 && N == 128 ? (size_t)2 * g.num_blocks * 3 * N * N : 0);
   p->total = o;
   return DPTNAV_OK;
 }
@@ -580,6 +585,31 @@ static int pack_wih_all(dptnav_ctx* c, Run& run) {
   return DPTNAV_OK;
 }
 
+// fragment-order copies of the attention in-projection weights of paths [first, first + n) -> dst[(path - first)][384 x 128]
+// (gemm_t.hip, training forward)
+static int pack_inw(dptnav_ctx* c, hipStream_t st, int first, int n, float* dst) {
+  GemmPackArgs a;
+  for (int i = 0; i < GEMM_PACK_MAX; ++i) a.src[i] = nullptr;
+  if (n > GEMM_PACK_MAX) return c->fail(DPTNAV_ERR_INVALID, "W_in pack: %d paths in one launch", n);
+  for (int i = 0; i < n; ++i) a.src[i] = c->pw[first + i].in_w;
+  a.rows = 3 * 128;
+  a.K = 128;
+  hipLaunchKernelGGL(gemm_pack_rows_kernel, dim3(16, n), dim3(256), 0, st, a, dst);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return c->fail(DPTNAV_ERR_HIP, "W_in pack: %s", hipGetErrorString(e));
+  return DPTNAV_OK;
+}
+static int pack_inw_all(dptnav_ctx* c, Run& run) {
+  if (!c->opt_gemm_t || c->cfg.num_features != 128 || c->cfg.arch != 0) return DPTNAV_OK;
+  const int npaths = 2 * c->cfg.num_blocks;
+  for (int first = 0; first < npaths; first += GEMM_PACK_MAX) {
+    const int n = std::min(GEMM_PACK_MAX, npaths - first);
+    if (int rc = pack_inw(c, run.st, first, n, run.ws + run.pl.winp + (size_t)first * 3 * 128 * 128)) return rc;
+  }
+  run.packed_inw = true;
+  return DPTNAV_OK;
+}
+
 // fcln.hip for one Linear (+ LayerNorm) launch.  Returns 1 when the launch went out, 0 when fcln_launch does not take the shape
 // (hipErrorInvalidValue, fcln.h: the caller then uses the GEMM engine; the sticky error is cleared), a negative DPTNAV error otherwise.
 static int try_fcln(dptnav_ctx* c, hipStream_t st, const FclnArgs& fa, int cat, const char* what) {
@@ -596,7 +626,7 @@ static int try_fcln(dptnav_ctx* c, hipStream_t st, const FclnArgs& fa, int cat, 
 }
 
 // dgrad_t.hip for one wide data-gradient launch (out = addend + A W, kin = 512 or 384; option dgrad_t).  `Wpacked`: the
-// fragment-order copy pack_dgrad_t made on the same stream.  Returns like try_fcln: 1 launched, 0 not taken (the caller uses the
+// fragment-order copy pack_bwd_weights made on the same stream.  Returns like try_fcln: 1 launched, 0 not taken (the caller uses the
 // GEMM engine), negative DPTNAV error.
 static int try_dgrad_t(dptnav_ctx* c, Run& run, int cat, const char* what, const float* A, int lda, int kin, const float* Wpacked,
                        const float* addend, float* out, int64_t M) {
@@ -621,36 +651,70 @@ static int try_dgrad_t(dptnav_ctx* c, Run& run, int cat, const char* what, const
   const int e = c->fail(DPTNAV_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)rc));
   return e < 0 ? e : -e;
 }
-// ... and the copies it reads: one or two [kin][128] weights -> dst (weights change every step: packed where they are used)
-static int pack_dgrad_t(dptnav_ctx* c, hipStream_t st, const float* w0, const float* w1, int kin, float* dst) {
-  if (!c->opt_dgrad_t) return DPTNAV_OK;
-  const int rc = dgrad_t_pack_launch(st, w0, w1, kin, dst);
-  if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "dgrad_t weight pack: %s", hipGetErrorString((hipError_t)rc));
+// Fragment-order weight copies the backward's dedicated kernels read (dgrad_t.hip, dgrad_r.hip): one slot of BWD_PACK_FLOATS per
+// path in the backward workspace -- [W_ih fwd | W_ih rev | in_proj_weight | out_proj.weight | ffn.1.weight].  dptnav_train_backward
+// fills the slots of ALL paths with four launches at its start (weights change every step, so once per step); the path-level entry
+// point packs the one path it runs into slot 0.  (Packed where they are used -- two to four 10-us launches in front of every
+// data-gradient launch -- they were 120 launches and 0.6 ms of each stream's chain per step.)
+constexpr size_t BWD_PACK_WIH = 0, BWD_PACK_INW = (size_t)2 * 512 * 128, BWD_PACK_OUTW = BWD_PACK_INW + (size_t)384 * 128,
+                 BWD_PACK_FFNW = BWD_PACK_OUTW + (size_t)128 * 128, BWD_PACK_FLOATS = BWD_PACK_FFNW + (size_t)128 * 256;
+static int pack_bwd_weights(dptnav_ctx* c, hipStream_t st, int first, int n, float* dst) {      // paths [first, first + n) -> slots 0 .. n - 1
+  if (c->cfg.num_features != 128 || c->cfg.arch != 0 || (!c->opt_dgrad_t && !c->opt_dgrad_r)) return DPTNAV_OK;
+  if (2 * n > DGRAD_PACK_MAX || n > DGRAD_R_PACK_MAX) return c->fail(DPTNAV_ERR_INVALID, "backward weight pack: %d paths in one launch", n);
+  const float* src[DGRAD_PACK_MAX];
+  long long off[DGRAD_PACK_MAX];
+  int rc = 0;
+  if (c->opt_dgrad_t) {
+    for (int i = 0; i < n; ++i) {
+      const PathWeights& w = c->pw[first + i];
+      src[2 * i] = w.w_ih[0];
+      src[2 * i + 1] = w.ndir == 2 ? w.w_ih[1] : nullptr;
+      off[2 * i] = (long long)(i * BWD_PACK_FLOATS + BWD_PACK_WIH);
+      off[2 * i + 1] = off[2 * i] + 512 * 128;
+    }
+    rc = dgrad_t_pack_launch(st, src, off, 2 * n, 512, dst);
+    for (int i = 0; i < n && rc == 0; ++i) {
+      src[i] = c->pw[first + i].in_w;
+      off[i] = (long long)(i * BWD_PACK_FLOATS + BWD_PACK_INW);
+    }
+    if (rc == 0) rc = dgrad_t_pack_launch(st, src, off, n, 384, dst);
+  }
+  if (rc == 0 && c->opt_dgrad_r) {
+    for (int i = 0; i < n; ++i) {
+      src[i] = c->pw[first + i].out_w;
+      off[i] = (long long)(i * BWD_PACK_FLOATS + BWD_PACK_OUTW);
+    }
+    rc = dgrad_r_pack_launch(st, src, off, n, 128, dst);
+    for (int i = 0; i < n; ++i) {
+      const PathWeights& w = c->pw[first + i];
+      src[i] = w.ndir == 2 ? w.ffn_w : nullptr;      // [128][256] only with both directions
+      off[i] = (long long)(i * BWD_PACK_FLOATS + BWD_PACK_FFNW);
+    }
+    if (rc == 0) rc = dgrad_r_pack_launch(st, src, off, n, 256, dst);
+  }
+  if (rc != 0) return c->fail(DPTNAV_ERR_HIP, "backward weight pack: %s", hipGetErrorString((hipError_t)rc));
   return DPTNAV_OK;
 }
 
-// dgrad_r.hip for one K = 128 data gradient with its weight / bias gradient riding (option dgrad_r): packs W on the stream, launches,
+// dgrad_r.hip for one K = 128 data gradient with its weight / bias gradient riding (option dgrad_r): `wpacked` from pack_bwd_weights;
 // leaves the partial tiles in `slab` / `colslab` and their number in *grid.  Returns like try_fcln.
-static int try_dgrad_r(dptnav_ctx* c, Run& run, int cat, const char* what, const float* A, const float* W, int nout, bool gate,
-                       const float* X, float* out, int64_t M, float* wpacked, float* slab, float* colslab, int max_slabs, int* grid) {
+static int try_dgrad_r(dptnav_ctx* c, Run& run, int cat, const char* what, const float* A, const float* wpacked, int nout, bool gate,
+                       const float* X, float* out, int64_t M, float* slab, float* colslab, int max_slabs, int* grid) {
   if (!c->opt_dgrad_r) return 0;
   if (int rc = inject_failure(c, what)) return rc < 0 ? rc : -rc;
   if (run.slot + 1 > QUEUE_SLOTS) {
     const int e = c->fail(DPTNAV_ERR_INVALID, "%s: ticket counters exhausted", what);
     return e < 0 ? e : -e;
   }
-  int rc = dgrad_r_pack_launch(run.st, W, nout, wpacked);
-  if (rc == 0) {
-    DgradRArgs a;
-    a.A = A; a.Wpacked = wpacked; a.X = X; a.out = out; a.M = M; a.nout = nout; a.relu_gate = gate;
-    a.slab = slab; a.colslab = colslab; a.max_slabs = max_slabs;
-    unsigned* const queue = run.take_queue(1);
-    a.queue = c->opt_deterministic ? nullptr : queue;
-    ProfScope ps(c, cat, run.st);
-    rc = dgrad_r_launch(run.st, a, c->num_cus, grid);
-    if (rc == 0) return 1;
-    run.slot -= 1;
-  }
+  DgradRArgs a;
+  a.A = A; a.Wpacked = wpacked; a.X = X; a.out = out; a.M = M; a.nout = nout; a.relu_gate = gate;
+  a.slab = slab; a.colslab = colslab; a.max_slabs = max_slabs;
+  unsigned* const queue = run.take_queue(1);
+  a.queue = c->opt_deterministic ? nullptr : queue;
+  ProfScope ps(c, cat, run.st);
+  const int rc = dgrad_r_launch(run.st, a, c->num_cus, grid);
+  if (rc == 0) return 1;
+  run.slot -= 1;
   if (rc == (int)hipErrorInvalidValue) {
     (void)hipGetLastError();
     return 0;
@@ -719,9 +783,30 @@ int run_path(dptnav_ctx* c, Run& run, int block, int path, const float* x_in, fl
   }
   // K1: qkv = x W_in^T + b_in                                  (nn.MultiheadAttention in-projection)
   if (dptn && !fused) {
-    ALoadDense al{x_in, M, N, BM};
-    EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
-    if (int rc = launch_gemm<N, 3, WR, WC>(c, run, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, al, ep)) return rc;
+    int done = 0;
+    if constexpr (N == 128) {
+      if (pb.train && c->opt_gemm_t) {      // training forward: gemm_t.hip on the fragment-order copy of W_in (packed here, on the stream)
+        if (int rc = inject_failure(c, "qkv gemm")) return rc;
+        if (run.slot + 1 > QUEUE_SLOTS) return c->fail(DPTNAV_ERR_INVALID, "qkv gemm: ticket counters exhausted");
+        float* wp = ws + pl.winp + (run.packed_inw ? (size_t)(2 * block + path) * 3 * N * N : 0);
+        if (!run.packed_inw)
+          if (int rc = pack_inw(c, st, 2 * block + path, 1, wp)) return rc;
+        GemmTArgs ga;
+        ga.A = x_in; ga.Wpacked = wp; ga.bias = w.in_b; ga.out = qkv; ga.M = M; ga.nout = 3 * N;
+        unsigned* const queue = run.take_queue(1);
+        ga.queue = c->opt_deterministic ? nullptr : queue;
+        ProfScope ps(c, CAT_QKV, st);
+        const int rc = gemm_t_launch(st, ga, c->num_cus);
+        if (rc == 0) done = 1;
+        else if (rc == (int)hipErrorInvalidValue) { (void)hipGetLastError(); run.slot -= 1; }
+        else return c->fail(DPTNAV_ERR_HIP, "qkv gemm: %s", hipGetErrorString((hipError_t)rc));
+      }
+    }
+    if (!done) {
+      ALoadDense al{x_in, M, N, BM};
+      EpiBiasStore ep{qkv, w.in_b, M, 3 * N, BM, 3 * N};
+      if (int rc = launch_gemm<N, 3, WR, WC>(c, run, CAT_QKV, "qkv gemm", w.in_w, ntiles, 1, al, ep)) return rc;
+    }
   }
   // K2: softmax(Q K^T / sqrt(dh)) V per (sequence, head)
   if (dptn && !fused)
@@ -1096,7 +1181,7 @@ int make_bwd_plan(dptnav_ctx* c, int B, int S, BwdPlan* p, int64_t L = 0, int Tv
   p->dg3 = take((size_t)MD * 2 * 4 * H);
   p->slab2 = take((size_t)BWD_SLAB_WGS * 512 * 128);
   p->queue2 = take(QUEUE_SLOTS);
-  p->wiht = take((size_t)4 * 512 * 128);      // + the rider launches' weight (dgrad_r.hip)
+  p->wiht = take(g.arch == 0 && N == 128 ? (size_t)2 * g.num_blocks * BWD_PACK_FLOATS : 0);      // pack_bwd_weights
   p->lnp = take((size_t)BWD_LNP_WGS * 8 * N);      // LayerNorm (2N) or decoder-tap (8N) partials per workgroup
   p->dxa = take((size_t)M * N);                     // gradient ping-pong between paths
   p->dxb = take((size_t)M * N);
@@ -1127,6 +1212,7 @@ struct BwdRun {
   hipEvent_t ev_bptt = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
   bool wg_pending[3] = {false, false, false};
   int dg_sel = 0, side_slot = 0;
+  bool packed_all = false;           // ws + pl.wiht holds the fragment-order weight copies of ALL paths (dptnav_train_backward); else slot 0 = this path
   unsigned* take_queue_side(int n) {   // own counters: the main stream re-zeroes its region while side launches may be in flight
     if (side_slot + n > QUEUE_SLOTS) return nullptr;        // the caller fails the launch (as launch_gemm does for `slot`)
     unsigned* q = reinterpret_cast<unsigned*>(ws + pl.queue2) + side_slot;
@@ -1372,12 +1458,6 @@ int run_path_backward_dprnn(dptnav_ctx* c, BwdRun& br, int block, int path, cons
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      if (d == 0)
-        if (int rc = pack_dgrad_t(c, st, w.w_ih[0], nd == 2 ? w.w_ih[1] : nullptr, 512, br.ws + br.pl.wiht)) return rc;
-      const int t = try_dgrad_t(c, run, CAT_LSTM_PRE, "d x", DG + d * 512, nd * 512, 512, br.ws + br.pl.wiht + (size_t)d * 512 * 128,
-                                d == 0 ? d_out : d_in, d_in, M);
-      if (t < 0) return -t;
-      if (t) continue;
       ALoadCols al{DG, M, nd * 512, d * 512, 32};
       EpiAddMaskStoreT<true, false> ep{d_in, d == 0 ? d_out : d_in, nullptr, M, N, 32, N};
       if (int rc = launch_gemm<512, 1, 1, 4, true>(c, run, CAT_LSTM_PRE, "d x", w.w_ih[d], ntiles, 1, al, ep, nullptr, N)) return rc;
@@ -1418,6 +1498,12 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   float *DZ = br.ws + br.pl.dz, *DHb = br.ws + br.pl.dh, *DG = br.ws + br.pl.dg, *DY1 = br.ws + br.pl.dy1,
         *DATT = br.ws + br.pl.datt, *DQKV = br.ws + br.pl.dqkv, *LNP = br.ws + br.pl.lnp;
   const int64_t ntiles = (M + 31) / 32, ntiles_n = (M + BMn - 1) / BMn;
+  // fragment-order weight copies of this path (pack_bwd_weights): made for all paths by dptnav_train_backward, or here into slot 0
+  float* const wpk = br.ws + br.pl.wiht + (br.packed_all ? (size_t)(2 * block + path) * BWD_PACK_FLOATS : 0);
+  if constexpr (N == 128) {
+    if (!br.packed_all)
+      if (int rc = pack_bwd_weights(c, st, 2 * block + path, 1, wpk)) return rc;
+  }
   Run run;   // the GEMM engine takes its ticket counters from a Run: alias it onto the backward workspace
   run.ws = br.ws;
   run.pl = Plan{};
@@ -1481,9 +1567,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
         EpiAddMaskStoreT<false, true> ep{DHb, nullptr, hc, M, 2 * LSTM_H, 32, 2 * LSTM_H};
         float* slab = br.ws + br.pl.slab;
         int rgrid = 0;
-        const int t = try_dgrad_r(c, run, CAT_FFN, "d h + d ffn weight", DZ, w.ffn_w, 2 * LSTM_H, true, hc, DHb, M,
-                                  br.ws + br.pl.wiht + (size_t)3 * 512 * 128, slab, slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, BWD_SLAB_WGS,
-                                  &rgrid);
+        const int t = try_dgrad_r(c, run, CAT_FFN, "d h + d ffn weight", DZ, wpk + BWD_PACK_FFNW, 2 * LSTM_H, true, hc, DHb, M, slab,
+                                  slab + (size_t)BWD_SLAB_WGS * N * 2 * LSTM_H, BWD_SLAB_WGS, &rgrid);
         if (t < 0) return -t;
         // (grid known only after the occupancy query inside: the column-sum rows go behind BWD_SLAB_WGS partial tiles)
         WgradRider<2 * LSTM_H, ALoadColsReLU, true> rd{ALoadColsReLU{hc, M, 2 * LSTM_H, 0, 32}, slab,
@@ -1600,9 +1685,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   run.slot = br.slot;
   for (int d = 0; d < nd; ++d) {
     if constexpr (N == 128) {
-      if (d == 0)
-        if (int rc = pack_dgrad_t(c, st, w.w_ih[0], nd == 2 ? w.w_ih[1] : nullptr, 512, br.ws + br.pl.wiht)) return rc;
-      const int t = try_dgrad_t(c, run, CAT_LSTM_PRE, "d y1", DG + d * 512, nd * 512, 512, br.ws + br.pl.wiht + (size_t)d * 512 * 128,
+      const int t = try_dgrad_t(c, run, CAT_LSTM_PRE, "d y1", DG + d * 512, nd * 512, 512, wpk + BWD_PACK_WIH + (size_t)d * 512 * 128,
                                 d == 0 ? DZ : DY1, DY1, M);
       if (t < 0) return -t;
       if (t) continue;
@@ -1647,8 +1730,8 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
       EpiAddMaskStoreT<false, false> ep{DATT, nullptr, nullptr, M, N, 32, N};
       float* slab = br.ws + br.pl.slab;
       int rgrid = 0;
-      const int t = try_dgrad_r(c, run, CAT_OUTPROJ, "d att + d out weight", DZ, w.out_w, N, false, att, DATT, M,
-                                br.ws + br.pl.wiht + (size_t)3 * 512 * 128, slab, slab + (size_t)BWD_SLAB_WGS * N * N, BWD_SLAB_WGS, &rgrid);
+      const int t = try_dgrad_r(c, run, CAT_OUTPROJ, "d att + d out weight", DZ, wpk + BWD_PACK_OUTW, N, false, att, DATT, M, slab,
+                                slab + (size_t)BWD_SLAB_WGS * N * N, BWD_SLAB_WGS, &rgrid);
       if (t < 0) return -t;
       WgradRider<N, ALoadDense, true> rd{ALoadDense{att, M, N, 32}, slab, slab + (size_t)BWD_SLAB_WGS * N * N, M};
       if (!t)
@@ -1733,9 +1816,7 @@ int run_path_backward(dptnav_ctx* c, BwdRun& br, int block, int path, const floa
   {
     int t = 0;
     if constexpr (N == 128) {      // d x = dz + d qkv W_in (K = 384) by dgrad_t.hip
-      float* wp = br.ws + br.pl.wiht + (size_t)2 * 512 * 128;
-      if (int rc = pack_dgrad_t(c, st, w.in_w, nullptr, 384, wp)) return rc;
-      t = try_dgrad_t(c, run, CAT_QKV, "d x", DQKV, 3 * N, 384, wp, DZ, d_in, M);
+      t = try_dgrad_t(c, run, CAT_QKV, "d x", DQKV, 3 * N, 384, wpk + BWD_PACK_INW, DZ, d_in, M);
       if (t < 0) return -t;
     }
     if (!t) {
@@ -2538,6 +2619,7 @@ int dptnav_train_forward(dptnav_handle h, const float* mix, const float* e1, con
                                sp.Bh[i], T, Tv, tb[i] + mt.E, tb[i] + mt.X0, tb[i] + mt.vid)))
       return rc;
     if (int rc = h->cfg.num_features == 128 ? pack_wih_all<128>(h, run[i]) : pack_wih_all<64>(h, run[i])) return rc;
+    if (int rc = pack_inw_all(h, run[i])) return rc;
   }
   // the halves advance in lock step on the host; their recurrences are chained by events as in dptnav_forward
   bool have_prev = false;
@@ -2631,6 +2713,11 @@ int dptnav_train_backward(dptnav_handle h, const float* mix, const float* e1, co
       br[i].ev_wg[1] = h->ev_side[i][2];
       br[i].ev_wg[2] = h->ev_side[i][3];
     }
+    for (int first = 0; first < 2 * nb; first += DGRAD_R_PACK_MAX / 2) {      // weight copies of every path, once per step and half
+      const int n = std::min(DGRAD_R_PACK_MAX / 2, 2 * nb - first);
+      if (int rc = pack_bwd_weights(h, si[i], first, n, br[i].ws + bp.wiht + (size_t)first * BWD_PACK_FLOATS)) return rc;
+    }
+    br[i].packed_all = true;
     run[i].ws = br[i].ws;
     run[i].pl = Plan{};
     run[i].pl.queue = bp.queue;
@@ -2729,6 +2816,7 @@ int dptnav_set_option(dptnav_handle h, const char* key, int value) {
   else if (k == "attn_v2") h->opt_attn_v2 = value != 0;
   else if (k == "dgrad_t") h->opt_dgrad_t = value != 0;
   else if (k == "dgrad_r") h->opt_dgrad_r = value != 0;
+  else if (k == "gemm_t") h->opt_gemm_t = value != 0;
   else if (k == "fuse_ffn") h->opt_fuse_ffn = value != 0;
   else if (k == "wgrad2") h->opt_wgrad2 = value != 0;
   else if (k == "ln_tape") h->opt_ln_tape = value != 0;

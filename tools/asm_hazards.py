@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "speech_separation_amd", "csrc")
-FILES = ["dgrad_t.hip", "dgrad_r.hip", "attn_block2.hip", "lstm16x.hip", "fcln.hip"]
+FILES = ["dgrad_t.hip", "dgrad_r.hip", "gemm_t.hip", "attn_block2.hip", "lstm16x.hip", "fcln.hip"]
 NO_VGPR_FORM = {"dgrad_r.hip"}
 
 
@@ -66,7 +66,7 @@ def main():
                 n_store += 1
                 if not lines[i + 1].startswith("s_nop"):
                     bad.append(f"{src} {func}: wide store in inline assembly without a wait state behind it: {ln} / {lines[i + 1]}")
-        if src == "dgrad_t.hip":
+        if src in ("dgrad_t.hip", "gemm_t.hip"):
             body = "\n".join(lines)
             for pat in ("v_accvgpr_", "scratch_"):
                 if pat in body:

@@ -60,7 +60,8 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
-      if (int rc = dgrad_r_pack_launch(nullptr, dW, nout, dWp)) { printf("pack rc %d\n", rc); return 1; }
+      { const float* srcs[1] = {dW}; const long long offs[1] = {0};
+        if (int rc = dgrad_r_pack_launch(nullptr, srcs, offs, 1, nout, dWp)) { printf("pack rc %d\n", rc); return 1; } }
       DgradRArgs a;
       a.A = dA; a.Wpacked = dWp; a.X = dX; a.out = dout; a.M = M; a.nout = nout; a.relu_gate = gate;
       a.slab = dslab; a.colslab = dcol; a.max_slabs = max_slabs; a.queue = nullptr;

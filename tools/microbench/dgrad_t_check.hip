@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dadd, h.data(), (size_t)M * N * 4, hipMemcpyHostToDevice));
     for (size_t i = 0; i < (size_t)K * N; ++i) h[i] *= 0.05f;
     CK(hipMemcpy(dW, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice));
-    dgrad_t_pack_launch(nullptr, dW, nullptr, K, dWp);
+    { const float* srcs[1] = {dW}; const long long offs[1] = {0}; dgrad_t_pack_launch(nullptr, srcs, offs, 1, K, dWp); }
     DgradTArgs a;
     a.A = dA; a.lda = lda; a.W = dWp; a.addend = dadd; a.out = dout; a.M = M; a.kin = K; a.queue = nullptr;
     hipEvent_t e0, e1;
@@ -92,7 +92,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dWp, hW.size() * 4));
-    if (int rc = dgrad_t_pack_launch(nullptr, dW, nullptr, K, dWp)) { printf("pack rc %d\n", rc); return 1; }
+    { const float* srcs[1] = {dW}; const long long offs[1] = {0};
+      if (int rc = dgrad_t_pack_launch(nullptr, srcs, offs, 1, K, dWp)) { printf("pack rc %d\n", rc); return 1; } }
     CK(hipMemcpy(dadd, hadd.data(), hadd.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> ref_out(hadd.size()), got(hadd.size());
     for (int col0 : {0, 512 - (K == 384 ? 128 : 0) * 0}) {
