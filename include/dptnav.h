@@ -304,6 +304,9 @@ int dptnav_dropout_mask(dptnav_handle h, int block, int path, int B, int S, floa
  *   "dgrad_r" (0/1, default 1): training backward, num_features = 128 -- the two K = 128 data gradients whose layer's weight / bias
  *                 gradient is formed on the same staged tiles (d att + dW_o + db_o, dptn.py:46-47; d h + dW_f + db_f behind the
  *                 ReLU, dptn.py:50) by dgrad_r.hip; 0 = the GEMM engine with its WgradRider.  Same sums in another association.
+ *   "gemm_t" (0/1, default 1): training forward, num_features = 128 -- the attention in-projection qkv = x W_in^T + b_in
+ *                 (dptn.py:16-21, 46) by gemm_t.hip (transposed product, accumulators started from the bias); 0 = the GEMM engine.
+ *                 Same sums in another association: outputs and gradients agree to fp32 rounding.
  *   "train_fuse_probe" (0/1, default 0): MEASUREMENT ONLY (tools/train_fuse_probe.py) -- the training forward runs the inference
  *                 attention block: no qkv / attention / LayerNorm tape is written and no dropout is applied.  While it is set
  *                 dptnav_train_backward and dptnav_train_path_backward return DPTNAV_ERR_INVALID. */
